@@ -1,0 +1,152 @@
+/*
+ * qsv.h -- C ABI of libqsv.so: MI355X (gfx950) state-vector gate application.
+ *
+ * This is the drop-in boundary for the gate-application hot path of the reference's
+ * simulators/{dv,cv}_simulator.  The reference has no FFI layer: its boundary is the duck-typed
+ * Python protocol `gate.apply(state)` (simulators/dv_simulator/simulator.py:47-52,
+ * simulators/cv_simulator/simulator.py:66-70).  Each entry point below names the reference
+ * code it replaces.  Python binds this header with ctypes (quantum_computations_amd/_lib.py);
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - All functions return an int status: QSV_OK (0) or a negative QSV_E* code; the message of
+ *    the most recent failure on the calling thread is returned by qsv_last_error().
+ *  - Amplitudes are complex128, interleaved (re, im) doubles -- the memory layout of a NumPy
+ *    complex128 array.  Matrices are row-major, interleaved complex.
+ *  - Qubit numbering is the reference's: qubit q of an n-qubit register is bit (n-1-q) of the
+ *    flat amplitude index (qubit 0 = most significant; `X(0)|000>` -> index 4).  For a k-qubit
+ *    matrix, qubits[0] is the most significant leg, matching expand_gate's kron(gate, I, ...) +
+ *    `targets` order (simulators/dv_simulator/numpy_quantum.py:243-247).
+ *  - A qsv_state is owned by the library and used from one host thread at a time; calls enqueue
+ *    work on the state's HIP stream and return without waiting unless they return data.
+ *    Distinct handles may be used concurrently from distinct threads.
+ *  - Host buffers passed in are only read/written during the call.  Randomness stays with the
+ *    caller (qsv_measure takes the uniform draw), so seeded runs and forced results reproduce.
+ */
+#ifndef QSV_H
+#define QSV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QSV_VERSION 100 /* 0.1.0 */
+
+enum {
+    QSV_OK = 0,
+    QSV_EINVAL = -1,  /* bad qubit / duplicate index / bad size -> Python ValueError (gates.py:9-19) */
+    QSV_ENOMEM = -2,  /* device allocation failed or view capacity too small -> MemoryError */
+    QSV_EHIP = -3,    /* HIP runtime error (no device, launch failure, ...) -> RuntimeError */
+    QSV_ESTATE = -4   /* wrong kind of state for this call (qubit vs qudit) -> TypeError */
+};
+
+/* Options for qsv_set_option. */
+enum {
+    QSV_OPT_SPECIALIZE = 1, /* 1 (default): diagonal / controlled / permutation matrices take the
+                               reduced-traffic kernels; 0: every gate runs the dense kernel */
+    QSV_OPT_UNROLL = 2,     /* work items in flight per thread (1,2,4,8); 0 = built-in default */
+    QSV_OPT_GRID_CAP = 3,   /* max workgroups per launch; 0 = one tile per workgroup */
+    QSV_OPT_NONTEMPORAL = 4 /* 1: nontemporal loads/stores in the streaming kernels */
+};
+
+typedef struct qsv_state qsv_state;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int qsv_version(void);
+const char *qsv_last_error(void);
+int qsv_device_count(int *count);
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+/* Allocate an n-qubit register on `device` initialised to |0...0> (n = 0 is the 1-element
+ * register [1.0] that parse_state(None) returns, simulators/dv_simulator/simulator.py:22). */
+int qsv_create(int n_qubits, int device, qsv_state **out);
+/* Wrap caller-owned device memory (e.g. a torch tensor's data_ptr()) holding `capacity_amps`
+ * complex128 slots; `hip_stream` is a hipStream_t (NULL = the default stream).  The register's
+ * amplitudes always start at dev_amps; measure/insert keep them there. */
+int qsv_create_view(int n_qubits, int device, void *dev_amps, uint64_t capacity_amps, void *hip_stream,
+                    qsv_state **out);
+int qsv_destroy(qsv_state *st);
+int qsv_set_stream(qsv_state *st, void *hip_stream);
+int qsv_set_option(qsv_state *st, int option, int64_t value);
+int qsv_num_qubits(const qsv_state *st, int *n_qubits);
+int qsv_num_amps(const qsv_state *st, uint64_t *n_amps);
+int qsv_device_ptr(qsv_state *st, void **dev_amps);
+int qsv_sync(qsv_state *st);
+
+/* ---- data movement ---------------------------------------------------------------------- */
+int qsv_set_basis(qsv_state *st, uint64_t index);
+int qsv_upload(qsv_state *st, const double *host_interleaved, uint64_t offset_amps, uint64_t count_amps);
+int qsv_download(qsv_state *st, double *host_interleaved, uint64_t offset_amps, uint64_t count_amps);
+int qsv_copy(qsv_state *dst, const qsv_state *src);
+/* Fill with pseudo-random complex normal amplitudes keyed by (seed, global amplitude index +
+ * index_offset) and leave the squared norm of what was written in *norm2 (may be NULL);
+ * qsv_scale() then normalises.  Used for states too large to come from the host. */
+int qsv_fill_random(qsv_state *st, uint64_t seed, uint64_t index_offset, double *norm2);
+int qsv_scale(qsv_state *st, double re, double im);
+
+/* ---- gate application: replaces Gate.apply -> expand_gate -> `gate @ state`
+ *      (simulators/dv_simulator/gates.py:44-54, numpy_quantum.py:243-247) ------------------- */
+int qsv_apply_1q(qsv_state *st, int q, const double m[8]);
+int qsv_apply_2q(qsv_state *st, int q0, int q1, const double m[32]);
+/* Diagonal gates (Z, RZ, P, Pdg, T, Tdg, CZ: gates.py:79-114,128-130): d = the diagonal. */
+int qsv_apply_diag_1q(qsv_state *st, int q, const double d[4]);
+int qsv_apply_diag_2q(qsv_state *st, int q0, int q1, const double d[8]);
+/* CX (gates.py:116-126) and SWAP (gates.py:132-134) as pure amplitude moves. */
+int qsv_apply_cx(qsv_state *st, int control, int target);
+int qsv_apply_swap(qsv_state *st, int q0, int q1);
+/* `m` (2x2) on `target` for amplitudes whose `controls` are all 1 (add_control, numpy_quantum.py:250). */
+int qsv_apply_controlled_1q(qsv_state *st, int n_controls, const int *controls, int target, const double m[8]);
+/* Multiply the amplitudes whose `qubits` are all 1 by (re, im): multi-controlled phase / Z. */
+int qsv_apply_mcphase(qsv_state *st, int n_qubits, const int *qubits, double re, double im);
+/* Generic k-qubit matrix (2^k x 2^k), 1 <= k <= 6: Gate(indices, matrix).apply (gates.py:7-54). */
+int qsv_apply_kq(qsv_state *st, int k, const int *qubits, const double *m);
+/* Qubit-axis permutation of the ket: permute_tensor_product (numpy_quantum.py:227-240); the qubit
+ * at position j moves to position new_ordering[j]. */
+int qsv_permute(qsv_state *st, const int *new_ordering);
+
+/* ---- measurement / insertion: replace M.apply (gates.py:165-186), Insert.apply (:145-153) - */
+/* Projects qubit q on eig0 / eig1 (each 2 complex numbers, used UNCONJUGATED exactly as the
+ * reference does), leaves p0 = |res0|^2, p1 = |res1|^2, picks outcome = forced if forced is 0/1,
+ * else (u01 < p0/(p0+p1) ? 0 : 1), and shrinks the register to the normalised (n-1)-qubit ket. */
+int qsv_measure(qsv_state *st, int q, const double eig0[4], const double eig1[4], int forced, double u01,
+                int *outcome, double *p0, double *p1);
+/* The two halves of qsv_measure, for callers that draw the outcome themselves between them (the Python
+ * layer calls np.random.choice exactly as gates.py:183 does): the reduction without collapsing, and the
+ * collapse onto `eig` with the result multiplied by `scale` (1/norm of the chosen branch). */
+int qsv_measure_probs(qsv_state *st, int q, const double eig0[4], const double eig1[4], double *p0, double *p1);
+int qsv_collapse(qsv_state *st, int q, const double eig[4], double scale);
+/* Grows the register: new qubit with amplitudes amp[0..1] (complex) at position q. */
+int qsv_insert(qsv_state *st, int q, const double amp[4]);
+
+/* ---- read-out (npq.norm, numpy_quantum.py:131-132; |amp|^2 of chosen indices) -------------- */
+int qsv_norm2(qsv_state *st, double *out);
+int qsv_probabilities(qsv_state *st, const uint64_t *indices, int count, double *out);
+/* <a|b> with a conjugated: the ket-ket branch of npq.fidelity (numpy_quantum.py:151-152). */
+int qsv_inner(qsv_state *a, qsv_state *b, double *re, double *im);
+
+/* ---- d-level mode registers: the "d x d (d^2 x d^2) operator along mode axes" contraction of
+ *      cv_simulator (np.tensordot at simulators/cv_simulator/utils.py:15,37; gates.py:73,160) --- */
+int qsv_create_qudit(int n_modes, int d, int device, qsv_state **out);
+int qsv_create_qudit_view(int n_modes, int d, int device, void *dev_amps, uint64_t capacity_amps,
+                          void *hip_stream, qsv_state **out);
+int qsv_qudit_shape(const qsv_state *st, int *n_modes, int *d);
+int qsv_apply_mode1(qsv_state *st, int mode, const double *m /* d x d */);
+int qsv_apply_mode1_diag(qsv_state *st, int mode, const double *diag /* d */);
+int qsv_apply_mode2(qsv_state *st, int mode0, int mode1, const double *m /* d^2 x d^2 */);
+int qsv_apply_mode2_diag(qsv_state *st, int mode0, int mode1, const double *diag /* d^2 */);
+/* out[l, :, r] = M @ in[l, :, r] on a raw (L, d_in, R) device tensor -> (L, d_out, R): the exact
+ * tensordot+moveaxis of whittaker_shannon / rotation (cv_simulator/utils.py:9-39) on an MPS site. */
+int qsv_tensor_apply_axis(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L,
+                          uint64_t d_in, uint64_t d_out, uint64_t R, const double *m /* d_out x d_in */);
+
+/* ---- timing on the state's stream (HIP events), for bench.py's roofline figures ----------- */
+int qsv_timer_start(qsv_state *st);
+int qsv_timer_stop(qsv_state *st, float *elapsed_ms); /* records, synchronises the event, returns ms */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QSV_H */

@@ -1,0 +1,630 @@
+// C ABI of libqsv.so (include/qsv.h): argument validation, qubit -> bit mapping, kernel selection.
+// The device work lives in qsv_kernels.hip (qubits) and qsv_qudit.hip (d-level modes).
+
+#include "qsv_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+bool valid(const qsv_state *st) { return st != nullptr; }
+
+// reference convention: qubit q of n <-> bit n-1-q of the flat index
+inline int bit_of(const qsv_state *st, int q) { return st->n - 1 - q; }
+
+int check_qubits(const qsv_state *st, int k, const int *qs) {
+    if (st->kind != 0) return qsv_fail(QSV_ESTATE, "this call needs a qubit register");
+    for (int i = 0; i < k; ++i) {
+        if (qs[i] < 0) return qsv_fail(QSV_EINVAL, "Non-negative index");
+        if (qs[i] >= st->n)
+            return qsv_fail(QSV_EINVAL, "qubit index " + std::to_string(qs[i]) + " out of range for a " +
+                                            std::to_string(st->n) + "-qubit register");
+        for (int j = 0; j < i; ++j)
+            if (qs[i] == qs[j]) return qsv_fail(QSV_EINVAL, "Indices must be distinct.");
+    }
+    return QSV_OK;
+}
+
+int alloc_workspace(qsv_state *st) {
+    QSV_HIP(hipMalloc(reinterpret_cast<void **>(&st->partials), sizeof(double) * 2 * QSV_REDUCE_BLOCKS));
+    QSV_HIP(hipHostMalloc(reinterpret_cast<void **>(&st->partials_host), sizeof(double) * 2 * QSV_REDUCE_BLOCKS,
+                          hipHostMallocDefault));
+    QSV_HIP(hipEventCreate(&st->ev_start));
+    QSV_HIP(hipEventCreate(&st->ev_stop));
+    return QSV_OK;
+}
+
+int create_common(int kind, int n, int d, uint64_t amps, int device, void *dev_amps, uint64_t capacity,
+                  void *stream, qsv_state **out) {
+    if (!out) return qsv_fail(QSV_EINVAL, "null output handle");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return qsv_fail(QSV_EHIP, std::string("no HIP device available: ") +
+                                      (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device < 0 || device >= count) return qsv_fail(QSV_EINVAL, "device ordinal out of range");
+    QSV_HIP(hipSetDevice(device));
+    qsv_state *st = new qsv_state();
+    st->device = device;
+    st->kind = kind;
+    st->n = n;
+    st->d = d;
+    st->amps = amps;
+    st->stream = static_cast<hipStream_t>(stream);
+    if (dev_amps) {
+        if (capacity < amps) {
+            delete st;
+            return qsv_fail(QSV_ENOMEM, "view capacity is smaller than the register");
+        }
+        st->data = static_cast<amp_t *>(dev_amps);
+        st->capacity = capacity;
+        st->owns_data = false;
+    } else {
+        if (hipMalloc(reinterpret_cast<void **>(&st->data), sizeof(amp_t) * amps) != hipSuccess) {
+            delete st;
+            return qsv_fail(QSV_ENOMEM, "device allocation of " + std::to_string(amps * sizeof(amp_t)) +
+                                            " bytes for the register failed");
+        }
+        st->capacity = amps;
+        st->owns_data = true;
+    }
+    int rc = alloc_workspace(st);
+    if (rc) {
+        qsv_destroy(st);
+        return rc;
+    }
+    if (st->owns_data) {
+        rc = qsvk_set_basis(st, 0);
+        if (rc) {
+            qsv_destroy(st);
+            return rc;
+        }
+    }
+    *out = st;
+    return QSV_OK;
+}
+
+bool is_one(double re, double im) { return re == 1.0 && im == 0.0; }
+bool is_zero(double re, double im) { return re == 0.0 && im == 0.0; }
+
+bool matrix_is_diagonal(int D, const double *m) {
+    for (int r = 0; r < D; ++r)
+        for (int c = 0; c < D; ++c)
+            if (r != c && !is_zero(m[2 * (r * D + c)], m[2 * (r * D + c) + 1])) return false;
+    return true;
+}
+
+bool matrix_equals(int D, const double *m, const double *ref_real) {
+    for (int i = 0; i < D * D; ++i)
+        if (m[2 * i] != ref_real[i] || m[2 * i + 1] != 0.0) return false;
+    return true;
+}
+
+// 1-qubit diagonal with the traffic-saving special cases: d0 == 1 touches only the bit = 1 half.
+int diag_1q_bits(qsv_state *st, int bit, const double d[4]) {
+    if (st->specialize && is_one(d[0], d[1])) {
+        if (is_one(d[2], d[3])) return QSV_OK;  // identity
+        return qsvk_phase(st, 1, &bit, d[2], d[3]);
+    }
+    return qsvk_diag(st, 1, &bit, 0, nullptr, d);
+}
+
+int diag_2q_bits(qsv_state *st, int b0, int b1, const double d[8]) {
+    if (st->specialize) {
+        const bool one0 = is_one(d[0], d[1]), one1 = is_one(d[2], d[3]), one2 = is_one(d[4], d[5]);
+        if (one0 && one1 && one2) {  // controlled phase: CZ touches a quarter of the register
+            if (is_one(d[6], d[7])) return QSV_OK;
+            const int both[2] = {b0, b1};
+            return qsvk_phase(st, 2, both, d[6], d[7]);
+        }
+        if (one0 && one1) return qsvk_diag(st, 1, &b1, 1, &b0, d + 4);  // control on leg 0
+        if (one0 && one2 && d[2] == d[6] && d[3] == d[7]) {
+            const double dd[4] = {1.0, 0.0, d[2], d[3]};  // acts on leg 1 only
+            return diag_1q_bits(st, b1, dd);
+        }
+    }
+    const int bits[2] = {b0, b1};
+    return qsvk_diag(st, 2, bits, 0, nullptr, d);
+}
+
+}  // namespace
+
+int qsv_fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+extern "C" {
+
+int qsv_version(void) { return QSV_VERSION; }
+
+const char *qsv_last_error(void) { return g_last_error.c_str(); }
+
+int qsv_device_count(int *count) {
+    if (!count) return qsv_fail(QSV_EINVAL, "null pointer");
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return qsv_fail(QSV_EHIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    return QSV_OK;
+}
+
+int qsv_create(int n_qubits, int device, qsv_state **out) {
+    if (n_qubits < 0 || n_qubits > 40) return qsv_fail(QSV_EINVAL, "n_qubits must be in 0..40");
+    return create_common(0, n_qubits, 2, 1ull << n_qubits, device, nullptr, 0, nullptr, out);
+}
+
+int qsv_create_view(int n_qubits, int device, void *dev_amps, uint64_t capacity_amps, void *hip_stream,
+                    qsv_state **out) {
+    if (n_qubits < 0 || n_qubits > 40) return qsv_fail(QSV_EINVAL, "n_qubits must be in 0..40");
+    if (!dev_amps) return qsv_fail(QSV_EINVAL, "null device pointer");
+    if (reinterpret_cast<uintptr_t>(dev_amps) % 16) return qsv_fail(QSV_EINVAL, "device pointer must be 16-byte aligned");
+    return create_common(0, n_qubits, 2, 1ull << n_qubits, device, dev_amps, capacity_amps, hip_stream, out);
+}
+
+int qsv_destroy(qsv_state *st) {
+    if (!st) return QSV_OK;
+    (void)hipSetDevice(st->device);
+    if (st->stream || st->data) (void)hipStreamSynchronize(st->stream);
+    if (st->owns_data && st->data) (void)hipFree(st->data);
+    if (st->partials) (void)hipFree(st->partials);
+    if (st->partials_host) (void)hipHostFree(st->partials_host);
+    if (st->dev_matrix) (void)hipFree(st->dev_matrix);
+    if (st->ev_start) (void)hipEventDestroy(st->ev_start);
+    if (st->ev_stop) (void)hipEventDestroy(st->ev_stop);
+    delete st;
+    return QSV_OK;
+}
+
+int qsv_set_stream(qsv_state *st, void *hip_stream) {
+    if (!valid(st)) return qsv_fail(QSV_EINVAL, "null state");
+    QSV_HIP(hipStreamSynchronize(st->stream));
+    st->stream = static_cast<hipStream_t>(hip_stream);
+    return QSV_OK;
+}
+
+int qsv_set_option(qsv_state *st, int option, int64_t value) {
+    if (!valid(st)) return qsv_fail(QSV_EINVAL, "null state");
+    switch (option) {
+        case QSV_OPT_SPECIALIZE: st->specialize = value != 0; return QSV_OK;
+        case QSV_OPT_UNROLL:
+            if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+                return qsv_fail(QSV_EINVAL, "unroll must be 0, 1, 2, 4 or 8");
+            st->unroll = static_cast<int>(value);
+            return QSV_OK;
+        case QSV_OPT_GRID_CAP:
+            if (value < 0 || value > (1 << 30)) return qsv_fail(QSV_EINVAL, "bad grid cap");
+            st->grid_cap = static_cast<int>(value);
+            return QSV_OK;
+        case QSV_OPT_NONTEMPORAL: st->nontemporal = value != 0; return QSV_OK;
+        default: return qsv_fail(QSV_EINVAL, "unknown option");
+    }
+}
+
+int qsv_num_qubits(const qsv_state *st, int *n_qubits) {
+    if (!valid(st) || !n_qubits) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (st->kind != 0) return qsv_fail(QSV_ESTATE, "this call needs a qubit register");
+    *n_qubits = st->n;
+    return QSV_OK;
+}
+
+int qsv_num_amps(const qsv_state *st, uint64_t *n_amps) {
+    if (!valid(st) || !n_amps) return qsv_fail(QSV_EINVAL, "null pointer");
+    *n_amps = st->amps;
+    return QSV_OK;
+}
+
+int qsv_device_ptr(qsv_state *st, void **dev_amps) {
+    if (!valid(st) || !dev_amps) return qsv_fail(QSV_EINVAL, "null pointer");
+    *dev_amps = st->data;
+    return QSV_OK;
+}
+
+int qsv_sync(qsv_state *st) {
+    if (!valid(st)) return qsv_fail(QSV_EINVAL, "null state");
+    QSV_HIP(hipSetDevice(st->device));
+    QSV_HIP(hipStreamSynchronize(st->stream));
+    return QSV_OK;
+}
+
+int qsv_set_basis(qsv_state *st, uint64_t index) {
+    if (!valid(st)) return qsv_fail(QSV_EINVAL, "null state");
+    if (index >= st->amps) return qsv_fail(QSV_EINVAL, "basis index out of range");
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvk_set_basis(st, index);
+}
+
+int qsv_upload(qsv_state *st, const double *host, uint64_t offset, uint64_t count) {
+    if (!valid(st) || (!host && count)) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (offset > st->amps || count > st->amps - offset) return qsv_fail(QSV_EINVAL, "upload range out of bounds");
+    QSV_HIP(hipSetDevice(st->device));
+    QSV_HIP(hipMemcpyAsync(st->data + offset, host, sizeof(amp_t) * count, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));
+    return QSV_OK;
+}
+
+int qsv_download(qsv_state *st, double *host, uint64_t offset, uint64_t count) {
+    if (!valid(st) || (!host && count)) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (offset > st->amps || count > st->amps - offset) return qsv_fail(QSV_EINVAL, "download range out of bounds");
+    QSV_HIP(hipSetDevice(st->device));
+    QSV_HIP(hipMemcpyAsync(host, st->data + offset, sizeof(amp_t) * count, hipMemcpyDeviceToHost, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));
+    return QSV_OK;
+}
+
+int qsv_copy(qsv_state *dst, const qsv_state *src) {
+    if (!valid(dst) || !valid(src)) return qsv_fail(QSV_EINVAL, "null state");
+    if (dst->kind != src->kind || dst->d != src->d) return qsv_fail(QSV_ESTATE, "registers of different kinds");
+    if (src->amps > dst->capacity) return qsv_fail(QSV_ENOMEM, "destination register too small");
+    QSV_HIP(hipSetDevice(dst->device));
+    QSV_HIP(hipStreamSynchronize(src->stream));
+    QSV_HIP(hipMemcpyAsync(dst->data, src->data, sizeof(amp_t) * src->amps, hipMemcpyDeviceToDevice, dst->stream));
+    dst->n = src->n;
+    dst->amps = src->amps;
+    return QSV_OK;
+}
+
+int qsv_fill_random(qsv_state *st, uint64_t seed, uint64_t index_offset, double *norm2) {
+    if (!valid(st)) return qsv_fail(QSV_EINVAL, "null state");
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvk_fill_random(st, seed, index_offset, norm2);
+}
+
+int qsv_scale(qsv_state *st, double re, double im) {
+    if (!valid(st)) return qsv_fail(QSV_EINVAL, "null state");
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvk_scale(st, re, im);
+}
+
+// ---- gates ----------------------------------------------------------------------------------------
+
+int qsv_apply_1q(qsv_state *st, int q, const double m[8]) {
+    if (!valid(st) || !m) return qsv_fail(QSV_EINVAL, "null pointer");
+    int rc = check_qubits(st, 1, &q);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    const int bit = bit_of(st, q);
+    if (st->specialize && matrix_is_diagonal(2, m)) {
+        const double d[4] = {m[0], m[1], m[6], m[7]};
+        return diag_1q_bits(st, bit, d);
+    }
+    return qsvk_dense(st, 1, &bit, 0, nullptr, m);
+}
+
+int qsv_apply_2q(qsv_state *st, int q0, int q1, const double m[32]) {
+    if (!valid(st) || !m) return qsv_fail(QSV_EINVAL, "null pointer");
+    const int qs[2] = {q0, q1};
+    int rc = check_qubits(st, 2, qs);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    const int bits[2] = {bit_of(st, q0), bit_of(st, q1)};
+    if (st->specialize) {
+        if (matrix_is_diagonal(4, m)) {
+            const double d[8] = {m[0], m[1], m[10], m[11], m[20], m[21], m[30], m[31]};
+            return diag_2q_bits(st, bits[0], bits[1], d);
+        }
+        static const double CX[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0};
+        static const double XC[16] = {1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0};  // control = leg 1
+        static const double SW[16] = {1, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 1};
+        if (matrix_equals(4, m, CX)) return qsv_apply_cx(st, q0, q1);
+        if (matrix_equals(4, m, XC)) return qsv_apply_cx(st, q1, q0);
+        if (matrix_equals(4, m, SW)) return qsv_apply_swap(st, q0, q1);
+        // controlled-U with the control on leg 0: rows/cols 0,1 are the identity block
+        bool ctl0 = true;
+        for (int r = 0; r < 4 && ctl0; ++r)
+            for (int c = 0; c < 4; ++c) {
+                if (r >= 2 && c >= 2) continue;
+                const double want = (r == c) ? 1.0 : 0.0;
+                if (m[2 * (r * 4 + c)] != want || m[2 * (r * 4 + c) + 1] != 0.0) {
+                    ctl0 = false;
+                    break;
+                }
+            }
+        if (ctl0) {
+            const double u[8] = {m[20], m[21], m[22], m[23], m[28], m[29], m[30], m[31]};
+            return qsvk_dense(st, 1, &bits[1], 1, &bits[0], u);
+        }
+    }
+    return qsvk_dense(st, 2, bits, 0, nullptr, m);
+}
+
+int qsv_apply_diag_1q(qsv_state *st, int q, const double d[4]) {
+    if (!valid(st) || !d) return qsv_fail(QSV_EINVAL, "null pointer");
+    int rc = check_qubits(st, 1, &q);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    return diag_1q_bits(st, bit_of(st, q), d);
+}
+
+int qsv_apply_diag_2q(qsv_state *st, int q0, int q1, const double d[8]) {
+    if (!valid(st) || !d) return qsv_fail(QSV_EINVAL, "null pointer");
+    const int qs[2] = {q0, q1};
+    int rc = check_qubits(st, 2, qs);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    return diag_2q_bits(st, bit_of(st, q0), bit_of(st, q1), d);
+}
+
+int qsv_apply_cx(qsv_state *st, int control, int target) {
+    if (!valid(st)) return qsv_fail(QSV_EINVAL, "null state");
+    const int qs[2] = {control, target};
+    int rc = check_qubits(st, 2, qs);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    const int cbit = bit_of(st, control), tbit = bit_of(st, target);
+    static const double X[8] = {0, 0, 1, 0, 1, 0, 0, 0};
+    return qsvk_dense(st, 1, &tbit, 1, &cbit, X);
+}
+
+int qsv_apply_swap(qsv_state *st, int q0, int q1) {
+    if (!valid(st)) return qsv_fail(QSV_EINVAL, "null state");
+    const int qs[2] = {q0, q1};
+    int rc = check_qubits(st, 2, qs);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    const int b0 = bit_of(st, q0), b1 = bit_of(st, q1);
+    if (b0 >= QSV_LANE_BITS && b1 >= QSV_LANE_BITS && st->n >= QSV_LANE_BITS) return qsvk_pair_exchange(st, b0, b1);
+    static const double SW[32] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0,
+                                  0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0};
+    const int bits[2] = {b0, b1};
+    return qsvk_dense(st, 2, bits, 0, nullptr, SW);
+}
+
+int qsv_apply_controlled_1q(qsv_state *st, int n_controls, const int *controls, int target, const double m[8]) {
+    if (!valid(st) || !m || (n_controls > 0 && !controls)) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (n_controls < 0 || n_controls >= 64) return qsv_fail(QSV_EINVAL, "bad control count");
+    std::vector<int> qs(controls, controls + n_controls);
+    qs.push_back(target);
+    int rc = check_qubits(st, static_cast<int>(qs.size()), qs.data());
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    std::vector<int> cbits(n_controls);
+    for (int i = 0; i < n_controls; ++i) cbits[i] = bit_of(st, controls[i]);
+    const int tbit = bit_of(st, target);
+    if (st->n < QSV_LANE_BITS && n_controls + 1 > QSV_MAX_K)
+        return qsv_fail(QSV_EINVAL, "too many controls for a tiny register");
+    return qsvk_dense(st, 1, &tbit, n_controls, cbits.data(), m);
+}
+
+int qsv_apply_mcphase(qsv_state *st, int n_qubits, const int *qubits, double re, double im) {
+    if (!valid(st) || (n_qubits > 0 && !qubits)) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (n_qubits < 0 || n_qubits > 64) return qsv_fail(QSV_EINVAL, "bad qubit count");
+    int rc = check_qubits(st, n_qubits, qubits);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    std::vector<int> cbits(n_qubits);
+    for (int i = 0; i < n_qubits; ++i) cbits[i] = bit_of(st, qubits[i]);
+    return qsvk_phase(st, n_qubits, cbits.data(), re, im);
+}
+
+int qsv_apply_kq(qsv_state *st, int k, const int *qubits, const double *m) {
+    if (!valid(st) || !qubits || !m) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (k < 1 || k > QSV_MAX_K) return qsv_fail(QSV_EINVAL, "k must be in 1..6");
+    int rc = check_qubits(st, k, qubits);
+    if (rc) return rc;
+    if (k == 1) return qsv_apply_1q(st, qubits[0], m);
+    if (k == 2) return qsv_apply_2q(st, qubits[0], qubits[1], m);
+    QSV_HIP(hipSetDevice(st->device));
+    std::vector<int> bits(k);
+    for (int j = 0; j < k; ++j) bits[j] = bit_of(st, qubits[j]);
+    if (st->specialize && matrix_is_diagonal(1 << k, m)) {
+        std::vector<double> d(2ull << k);
+        const int D = 1 << k;
+        for (int i = 0; i < D; ++i) {
+            d[2 * i] = m[2 * (i * D + i)];
+            d[2 * i + 1] = m[2 * (i * D + i) + 1];
+        }
+        return qsvk_diag(st, k, bits.data(), 0, nullptr, d.data());
+    }
+    rc = qsvk_generic(st, k, bits.data(), m);
+    if (rc) return rc;
+    QSV_HIP(hipStreamSynchronize(st->stream));  // the matrix upload read the caller's buffer
+    return QSV_OK;
+}
+
+int qsv_permute(qsv_state *st, const int *new_ordering) {
+    if (!valid(st) || (st->n > 0 && !new_ordering)) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (st->kind != 0) return qsv_fail(QSV_ESTATE, "this call needs a qubit register");
+    const int n = st->n;
+    std::vector<int> seen(n, 0);
+    for (int j = 0; j < n; ++j) {
+        if (new_ordering[j] < 0 || new_ordering[j] >= n || seen[new_ordering[j]]++)
+            return qsv_fail(QSV_EINVAL, "new_ordering must be a permutation of all qubits");
+    }
+    QSV_HIP(hipSetDevice(st->device));
+    // qubit at position j moves to position new_ordering[j]:
+    // destination bit (n-1-new_ordering[j]) takes source bit (n-1-j)
+    std::vector<int> src_of_dst(n);
+    for (int j = 0; j < n; ++j) src_of_dst[n - 1 - new_ordering[j]] = n - 1 - j;
+    return qsvk_permute(st, src_of_dst.data());
+}
+
+// ---- measurement / insertion ------------------------------------------------------------------------
+
+int qsv_measure_probs(qsv_state *st, int q, const double eig0[4], const double eig1[4], double *p0, double *p1) {
+    if (!valid(st) || !eig0 || !eig1 || !p0 || !p1) return qsv_fail(QSV_EINVAL, "null pointer");
+    int rc = check_qubits(st, 1, &q);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvk_measure_probs(st, bit_of(st, q), eig0, eig1, p0, p1);
+}
+
+int qsv_collapse(qsv_state *st, int q, const double eig[4], double scale) {
+    if (!valid(st) || !eig) return qsv_fail(QSV_EINVAL, "null pointer");
+    int rc = check_qubits(st, 1, &q);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvk_collapse(st, bit_of(st, q), eig, scale);
+}
+
+int qsv_measure(qsv_state *st, int q, const double eig0[4], const double eig1[4], int forced, double u01,
+                int *outcome, double *p0, double *p1) {
+    if (!valid(st) || !eig0 || !eig1 || !outcome) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (forced < -1 || forced > 1) return qsv_fail(QSV_EINVAL, "Measurement results must be from 0 or 1");
+    double a = 0.0, b = 0.0;
+    int rc = qsv_measure_probs(st, q, eig0, eig1, &a, &b);
+    if (rc) return rc;
+    if (p0) *p0 = a;
+    if (p1) *p1 = b;
+    int s = forced;
+    if (s < 0) s = (u01 * (a + b) < a) ? 0 : 1;
+    const double pn = s ? b : a;
+    // the reference divides by the norm of the chosen branch; a zero-probability forced branch yields
+    // inf/nan there as well
+    const double scale = 1.0 / std::sqrt(pn);
+    rc = qsvk_collapse(st, bit_of(st, q), s ? eig1 : eig0, scale);
+    if (rc) return rc;
+    *outcome = s;
+    return QSV_OK;
+}
+
+int qsv_insert(qsv_state *st, int q, const double amp[4]) {
+    if (!valid(st) || !amp) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (st->kind != 0) return qsv_fail(QSV_ESTATE, "this call needs a qubit register");
+    if (q < 0 || q > st->n) return qsv_fail(QSV_EINVAL, "new_ordering must be a permutation of all qubits");
+    if (st->n + 1 > 40) return qsv_fail(QSV_EINVAL, "register too large");
+    QSV_HIP(hipSetDevice(st->device));
+    // after insertion the register has n+1 qubits and the new one is qubit q: bit (n+1)-1-q
+    return qsvk_insert(st, st->n - q, amp);
+}
+
+// ---- read-out ---------------------------------------------------------------------------------------
+
+int qsv_norm2(qsv_state *st, double *out) {
+    if (!valid(st) || !out) return qsv_fail(QSV_EINVAL, "null pointer");
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvk_norm2(st, out);
+}
+
+int qsv_probabilities(qsv_state *st, const uint64_t *indices, int count, double *out) {
+    if (!valid(st) || (count > 0 && (!indices || !out))) return qsv_fail(QSV_EINVAL, "null pointer");
+    for (int i = 0; i < count; ++i)
+        if (indices[i] >= st->amps) return qsv_fail(QSV_EINVAL, "amplitude index out of range");
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvk_probabilities(st, indices, count, out);
+}
+
+int qsv_inner(qsv_state *a, qsv_state *b, double *re, double *im) {
+    if (!valid(a) || !valid(b) || !re || !im) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (a->amps != b->amps) return qsv_fail(QSV_EINVAL, "registers of different sizes");
+    if (a->device != b->device) return qsv_fail(QSV_EINVAL, "registers on different devices");
+    QSV_HIP(hipSetDevice(a->device));
+    return qsvk_inner(a, b, re, im);
+}
+
+// ---- d-level modes ----------------------------------------------------------------------------------
+
+static int qudit_amps(int n_modes, int d, uint64_t *amps) {
+    if (n_modes < 1 || d < 2) return qsv_fail(QSV_EINVAL, "need n_modes >= 1 and d >= 2");
+    uint64_t a = 1;
+    for (int i = 0; i < n_modes; ++i) {
+        if (a > (1ull << 40) / static_cast<uint64_t>(d)) return qsv_fail(QSV_EINVAL, "register too large");
+        a *= static_cast<uint64_t>(d);
+    }
+    *amps = a;
+    return QSV_OK;
+}
+
+int qsv_create_qudit(int n_modes, int d, int device, qsv_state **out) {
+    uint64_t amps = 0;
+    int rc = qudit_amps(n_modes, d, &amps);
+    if (rc) return rc;
+    return create_common(1, n_modes, d, amps, device, nullptr, 0, nullptr, out);
+}
+
+int qsv_create_qudit_view(int n_modes, int d, int device, void *dev_amps, uint64_t capacity_amps, void *hip_stream,
+                          qsv_state **out) {
+    uint64_t amps = 0;
+    int rc = qudit_amps(n_modes, d, &amps);
+    if (rc) return rc;
+    if (!dev_amps) return qsv_fail(QSV_EINVAL, "null device pointer");
+    return create_common(1, n_modes, d, amps, device, dev_amps, capacity_amps, hip_stream, out);
+}
+
+int qsv_qudit_shape(const qsv_state *st, int *n_modes, int *d) {
+    if (!valid(st) || !n_modes || !d) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (st->kind != 1) return qsv_fail(QSV_ESTATE, "this call needs a qudit register");
+    *n_modes = st->n;
+    *d = st->d;
+    return QSV_OK;
+}
+
+static int check_modes(const qsv_state *st, int k, const int *modes) {
+    if (st->kind != 1) return qsv_fail(QSV_ESTATE, "this call needs a qudit register");
+    for (int i = 0; i < k; ++i) {
+        if (modes[i] < 0 || modes[i] >= st->n) return qsv_fail(QSV_EINVAL, "mode index out of range");
+        for (int j = 0; j < i; ++j)
+            if (modes[i] == modes[j]) return qsv_fail(QSV_EINVAL, "Indices must be distinct.");
+    }
+    return QSV_OK;
+}
+
+int qsv_apply_mode1(qsv_state *st, int mode, const double *m) {
+    if (!valid(st) || !m) return qsv_fail(QSV_EINVAL, "null pointer");
+    int rc = check_modes(st, 1, &mode);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvq_mode1(st, mode, m, false);
+}
+
+int qsv_apply_mode1_diag(qsv_state *st, int mode, const double *diag) {
+    if (!valid(st) || !diag) return qsv_fail(QSV_EINVAL, "null pointer");
+    int rc = check_modes(st, 1, &mode);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvq_mode1(st, mode, diag, true);
+}
+
+int qsv_apply_mode2(qsv_state *st, int mode0, int mode1, const double *m) {
+    if (!valid(st) || !m) return qsv_fail(QSV_EINVAL, "null pointer");
+    const int ms[2] = {mode0, mode1};
+    int rc = check_modes(st, 2, ms);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvq_mode2(st, mode0, mode1, m, false);
+}
+
+int qsv_apply_mode2_diag(qsv_state *st, int mode0, int mode1, const double *diag) {
+    if (!valid(st) || !diag) return qsv_fail(QSV_EINVAL, "null pointer");
+    const int ms[2] = {mode0, mode1};
+    int rc = check_modes(st, 2, ms);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvq_mode2(st, mode0, mode1, diag, true);
+}
+
+int qsv_tensor_apply_axis(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d_in,
+                          uint64_t d_out, uint64_t R, const double *m) {
+    if (!dev_in || !dev_out || !m) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (dev_in == dev_out) return qsv_fail(QSV_EINVAL, "in-place contraction is not supported: pass distinct buffers");
+    if (L == 0 || d_in == 0 || d_out == 0 || R == 0) return qsv_fail(QSV_EINVAL, "empty tensor");
+    return qsvq_tensor_axis(device, static_cast<hipStream_t>(hip_stream), static_cast<const amp_t *>(dev_in),
+                            static_cast<amp_t *>(dev_out), L, d_in, d_out, R, m);
+}
+
+// ---- timing -----------------------------------------------------------------------------------------
+
+int qsv_timer_start(qsv_state *st) {
+    if (!valid(st)) return qsv_fail(QSV_EINVAL, "null state");
+    QSV_HIP(hipSetDevice(st->device));
+    QSV_HIP(hipEventRecord(st->ev_start, st->stream));
+    return QSV_OK;
+}
+
+int qsv_timer_stop(qsv_state *st, float *elapsed_ms) {
+    if (!valid(st) || !elapsed_ms) return qsv_fail(QSV_EINVAL, "null pointer");
+    QSV_HIP(hipSetDevice(st->device));
+    QSV_HIP(hipEventRecord(st->ev_stop, st->stream));
+    QSV_HIP(hipEventSynchronize(st->ev_stop));
+    QSV_HIP(hipEventElapsedTime(elapsed_ms, st->ev_start, st->ev_stop));
+    return QSV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Internal declarations shared by the HIP translation units of libqsv.so (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "qsv.h"
+
+// One amplitude = complex128 = one 16-byte vector: exactly one dwordx4 per lane, 1 KiB per wave64 access.
+typedef double amp_t __attribute__((ext_vector_type(2)));
+
+constexpr int QSV_BLOCK = 256;    // threads per workgroup (4 waves, one per SIMD)
+constexpr int QSV_LANE_BITS = 6;  // index bits 0..5 are always spread over the 64 lanes of a wave
+constexpr int QSV_MAX_INS = 48;   // max inserted bit positions (high targets + high controls)
+constexpr int QSV_MAX_K = 6;      // generic k-qubit gates: 2^k x 2^k matrix, k <= 6
+
+// Arguments of the dense / phase kernels, passed by value (kernarg segment -> SGPRs).
+//
+// Work item w in [0, W) enumerates the "free" index bits.  deposit(w) re-inserts a zero at each position
+// pos[0] < pos[1] < ... (all >= QSV_LANE_BITS, so the six lane bits pass through and a wave always touches
+// 64 consecutive amplitudes) and ORs in or_mask (high controls fixed to 1).  The 2^KH amplitudes a thread
+// owns sit at deposit(w) + hoff[h]; the 2^KL "low" target bits are lane bits and are resolved by wave64
+// shuffles with lane masks lxor[x].
+struct GateArgs {
+    uint64_t W;
+    uint64_t or_mask;
+    uint64_t hoff[4];
+    int32_t nins;
+    uint32_t lane_ctrl;  // controls below QSV_LANE_BITS: a lane takes part iff (lane & lane_ctrl) == lane_ctrl
+    int32_t lbit[2];     // positions of the low target bits (bit j of l)
+    int32_t lxor[4];     // lane xor mask of low-bit combination x
+    uint8_t pos[QSV_MAX_INS];
+    double m[32];        // matrix in kernel order: row = (h << KL) | l, interleaved complex, row-major
+};
+
+// Diagonal gate on up to 2 target bits + controls: every enumerated amplitude is multiplied by
+// d[(bit(b0) << 1) | bit(b1)] (b1 < 0: single target, d[bit(b0)]).
+struct DiagArgs {
+    uint64_t W;
+    uint64_t or_mask;
+    int32_t nins;
+    uint32_t lane_ctrl;
+    int32_t b0, b1;
+    uint8_t pos[QSV_MAX_INS];
+    double d[8];
+};
+
+struct qsv_state {
+    int device = 0;
+    int kind = 0;            // 0 = qubits, 1 = qudits
+    int n = 0;               // qubits (kind 0) or modes (kind 1)
+    int d = 2;               // local dimension
+    uint64_t amps = 1;       // current number of amplitudes
+    uint64_t capacity = 0;   // slots available at `data`
+    amp_t *data = nullptr;
+    bool owns_data = false;
+    hipStream_t stream = nullptr;
+    // workspace
+    double *partials = nullptr;       // device: reduction partials (2 doubles per workgroup)
+    double *partials_host = nullptr;  // pinned host mirror
+    double *dev_matrix = nullptr;     // device: matrix / table of the generic kernels
+    size_t dev_matrix_bytes = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // options
+    int specialize = 1;
+    int unroll = 0;
+    int grid_cap = 0;
+    int nontemporal = 0;
+};
+
+constexpr int QSV_REDUCE_BLOCKS = 1024;
+
+// error plumbing (qsv_api.hip)
+int qsv_fail(int code, const std::string &msg);
+#define QSV_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return qsv_fail(QSV_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+    } while (0)
+
+// launchers (qsv_kernels.hip / qsv_qudit.hip); all enqueue on st->stream
+int qsvk_dense(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits, const double *m_user);
+int qsvk_pair_exchange(qsv_state *st, int bit_a, int bit_b);  // SWAP on two high bits (moves 1/2 of the state)
+int qsvk_diag(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits, const double *d_user);
+int qsvk_phase(qsv_state *st, int nctrl, const int *cbits, double re, double im);
+int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user);
+int qsvk_measure_probs(qsv_state *st, int bit, const double eig0[4], const double eig1[4], double *p0, double *p1);
+int qsvk_collapse(qsv_state *st, int bit, const double eig[4], double scale);
+int qsvk_insert(qsv_state *st, int bit, const double amp[4]);
+int qsvk_permute(qsv_state *st, const int *src_bit_of_dst_bit);
+int qsvk_norm2(qsv_state *st, double *out);
+int qsvk_inner(qsv_state *a, qsv_state *b, double *re, double *im);
+int qsvk_probabilities(qsv_state *st, const uint64_t *indices, int count, double *out);
+int qsvk_fill_random(qsv_state *st, uint64_t seed, uint64_t index_offset, double *norm2);
+int qsvk_scale(qsv_state *st, double re, double im);
+int qsvk_set_basis(qsv_state *st, uint64_t index);
+int qsvk_ensure_matrix(qsv_state *st, size_t bytes);
+int qsvk_scratch(qsv_state *st, uint64_t amps, amp_t **out);  // temporary device buffer (caller frees)
+
+int qsvq_mode1(qsv_state *st, int mode, const double *m, bool diag);
+int qsvq_mode2(qsv_state *st, int mode0, int mode1, const double *m, bool diag);
+int qsvq_tensor_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in,
+                     uint64_t d_out, uint64_t R, const double *m_host);

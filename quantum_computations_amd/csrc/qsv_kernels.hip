@@ -1,0 +1,879 @@
+// Qubit-register kernels of libqsv.so, written for gfx950 (MI355X, wave64) only.
+//
+// Every gate is one streaming pass over the complex128 register in HBM: the path is bandwidth-bound
+// (0.44-0.94 flop/B), so the kernels are organised around memory access, not arithmetic:
+//   * a wave always touches 64 consecutive amplitudes (1 KiB) per load/store instruction: index bits 0..5 are
+//     lane bits, whatever the target qubit;
+//   * target bits >= 6 are resolved in registers (a thread owns the 2 or 4 amplitudes of its group);
+//   * target bits < 6 lie inside a wavefront and are resolved with wave64 shuffles: each lane keeps its own
+//     amplitude, fetches its partners' with __shfl_xor and computes only its own row of the matrix;
+//   * control bits >= 6 are removed from the enumeration (amplitudes with control = 0 are never touched);
+//     control bits < 6 predicate lanes;
+//   * each thread keeps U independent work items in flight (8 x 16 B loads per lane) to cover HBM latency.
+// This replaces Gate.apply -> expand_gate -> dense mat-vec of the reference
+// (simulators/dv_simulator/gates.py:44-54, numpy_quantum.py:243-247).
+
+#include "qsv_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct cplx {
+    double re, im;
+};
+
+__device__ __forceinline__ amp_t cmul(cplx m, amp_t a) {
+    amp_t r;
+    r.x = m.re * a.x - m.im * a.y;
+    r.y = m.re * a.y + m.im * a.x;
+    return r;
+}
+
+// acc + m * a
+__device__ __forceinline__ amp_t cfma(cplx m, amp_t a, amp_t acc) {
+    amp_t r;
+    r.x = fma(m.re, a.x, fma(-m.im, a.y, acc.x));
+    r.y = fma(m.re, a.y, fma(m.im, a.x, acc.y));
+    return r;
+}
+
+template <bool NT>
+__device__ __forceinline__ amp_t ld(const amp_t *p) {
+    if constexpr (NT)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+}
+
+template <bool NT>
+__device__ __forceinline__ void st(amp_t *p, amp_t v) {
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
+__device__ __forceinline__ amp_t shfl_xor_amp(amp_t v, int lane_mask) {
+    amp_t r;
+    r.x = __shfl_xor(v.x, lane_mask, 64);
+    r.y = __shfl_xor(v.y, lane_mask, 64);
+    return r;
+}
+
+__device__ __forceinline__ uint64_t insert_zero(uint64_t w, int p) {
+    const uint64_t low = w & ((1ull << p) - 1ull);
+    return ((w >> p) << (p + 1)) | low;
+}
+
+template <class Args>
+__device__ __forceinline__ uint64_t deposit(uint64_t w, const Args &g) {
+    for (int j = 0; j < g.nins; ++j) w = insert_zero(w, g.pos[j]);
+    return w | g.or_mask;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Dense 1- and 2-qubit gates (optionally controlled).
+// ----------------------------------------------------------------------------------------------------
+template <int KH, int KL, int U, bool NT>
+__global__ __launch_bounds__(QSV_BLOCK) void k_dense(amp_t *__restrict__ a, const GateArgs g) {
+    constexpr int NH = 1 << KH, NL = 1 << KL, D = NH * NL;
+    const int lane = threadIdx.x & 63;
+    const bool lane_ok = (static_cast<uint32_t>(lane) & g.lane_ctrl) == g.lane_ctrl;
+
+    // This lane's value of the low target bits.
+    int l = 0;
+#pragma unroll
+    for (int j = 0; j < KL; ++j) l |= ((lane >> g.lbit[j]) & 1) << j;
+
+    // coef[h][hp][x] = M[(h, l)][(hp, l ^ x)]: the matrix row(s) this lane computes.  For KL == 0 the
+    // values are wave-uniform and stay in SGPRs; otherwise they are selected per lane once, up front.
+    cplx coef[NH][NH][NL];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int hp = 0; hp < NH; ++hp)
+#pragma unroll
+            for (int x = 0; x < NL; ++x) {
+                cplx c = {0.0, 0.0};
+#pragma unroll
+                for (int lc = 0; lc < NL; ++lc) {
+                    const int row = (h << KL) | lc, col = (hp << KL) | (lc ^ x);
+                    if (NL == 1 || l == lc) {
+                        c.re = g.m[2 * (row * D + col)];
+                        c.im = g.m[2 * (row * D + col) + 1];
+                    }
+                }
+                coef[h][hp][x] = c;
+            }
+
+    constexpr uint64_t TILE = static_cast<uint64_t>(QSV_BLOCK) * U;
+    const uint64_t ntiles = (g.W + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        amp_t v[U][NH];
+        uint64_t base[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t w = tile * TILE + static_cast<uint64_t>(u) * QSV_BLOCK + threadIdx.x;
+            ok[u] = w < g.W;  // W is a multiple of 64: uniform over the wave
+            base[u] = deposit(w, g);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                v[u][h] = amp_t{0.0, 0.0};
+                if (ok[u] && lane_ok) v[u][h] = ld<NT>(a + base[u] + g.hoff[h]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            amp_t out[NH];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) out[h] = amp_t{0.0, 0.0};
+#pragma unroll
+            for (int x = 0; x < NL; ++x)
+#pragma unroll
+                for (int hp = 0; hp < NH; ++hp) {
+                    const amp_t p = (x == 0) ? v[u][hp] : shfl_xor_amp(v[u][hp], g.lxor[x]);
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) out[h] = cfma(coef[h][hp][x], p, out[h]);
+                }
+            if (lane_ok) {
+#pragma unroll
+                for (int h = 0; h < NH; ++h) st<NT>(a + base[u] + g.hoff[h], out[h]);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Diagonal gates: one multiply per touched amplitude, natural (fully coalesced) enumeration.
+// ----------------------------------------------------------------------------------------------------
+template <int U, bool NT>
+__global__ __launch_bounds__(QSV_BLOCK) void k_diag(amp_t *__restrict__ a, const DiagArgs g) {
+    const int lane = threadIdx.x & 63;
+    const bool lane_ok = (static_cast<uint32_t>(lane) & g.lane_ctrl) == g.lane_ctrl;
+    const cplx d0 = {g.d[0], g.d[1]}, d1 = {g.d[2], g.d[3]}, d2 = {g.d[4], g.d[5]}, d3 = {g.d[6], g.d[7]};
+    constexpr uint64_t TILE = static_cast<uint64_t>(QSV_BLOCK) * U;
+    const uint64_t ntiles = (g.W + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        amp_t v[U];
+        uint64_t idx[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t w = tile * TILE + static_cast<uint64_t>(u) * QSV_BLOCK + threadIdx.x;
+            ok[u] = (w < g.W) && lane_ok;
+            idx[u] = deposit(w, g);
+            if (ok[u]) v[u] = ld<NT>(a + idx[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            const int s0 = static_cast<int>((idx[u] >> g.b0) & 1ull);
+            cplx d;
+            if (g.b1 < 0) {
+                d = s0 ? d1 : d0;
+            } else {
+                const int s1 = static_cast<int>((idx[u] >> g.b1) & 1ull);
+                d = s0 ? (s1 ? d3 : d2) : (s1 ? d1 : d0);
+            }
+            st<NT>(a + idx[u], cmul(d, v[u]));
+        }
+    }
+}
+
+// Generic-K diagonal: table of 2^K complex numbers in device memory, staged through LDS.
+__global__ __launch_bounds__(QSV_BLOCK) void k_diag_table(amp_t *__restrict__ a, uint64_t amps, int K,
+                                                         const uint8_t *__restrict__ bitpos /*K, device*/,
+                                                         const double *__restrict__ table) {
+    __shared__ double tab[2 << QSV_MAX_K];
+    __shared__ int bp[QSV_MAX_K];
+    for (int i = threadIdx.x; i < (2 << K); i += blockDim.x) tab[i] = table[i];
+    if (threadIdx.x < K) bp[threadIdx.x] = bitpos[threadIdx.x];
+    __syncthreads();
+    for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < amps;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        int sel = 0;
+        for (int j = 0; j < K; ++j) sel |= static_cast<int>((i >> bp[j]) & 1ull) << (K - 1 - j);
+        const cplx d = {tab[2 * sel], tab[2 * sel + 1]};
+        a[i] = cmul(d, a[i]);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Generic k-qubit dense gate (k <= 6) and the tiny-register path (n < 6): one thread per group, gathers
+// with arbitrary strides.  Correct for every layout; not bandwidth-tuned (DESIGN.md "kernels").
+// ----------------------------------------------------------------------------------------------------
+struct GenericArgs {
+    uint64_t W;
+    int32_t K;
+    uint8_t sorted_pos[QSV_MAX_K];  // ascending target bit positions (for deposit)
+    uint8_t leg_pos[QSV_MAX_K];     // bit position of matrix leg j (leg 0 = most significant)
+};
+
+template <int K>
+__global__ __launch_bounds__(QSV_BLOCK) void k_generic(amp_t *__restrict__ a, const GenericArgs g,
+                                                      const double *__restrict__ M) {
+    constexpr int D = 1 << K;
+    uint64_t off[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        uint64_t o = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if ((c >> (K - 1 - j)) & 1) o |= 1ull << g.leg_pos[j];
+        off[c] = o;
+    }
+    for (uint64_t w = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; w < g.W;
+         w += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        uint64_t base = w;
+#pragma unroll
+        for (int j = 0; j < K; ++j) base = insert_zero(base, g.sorted_pos[j]);
+        amp_t in[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) in[c] = a[base + off[c]];
+#pragma unroll 1
+        for (int r = 0; r < D; ++r) {
+            amp_t acc = {0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                const cplx m = {M[2 * (r * D + c)], M[2 * (r * D + c) + 1]};
+                acc = cfma(m, in[c], acc);
+            }
+            // rows are written as they are produced: all inputs are already in registers
+            uint64_t o = 0;
+            for (int j = 0; j < K; ++j)
+                if ((r >> (K - 1 - j)) & 1) o |= 1ull << g.leg_pos[j];
+            a[base + o] = acc;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Reductions, measurement, insertion, permutation, fills.
+// ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum of two doubles; result valid in thread 0.
+__device__ __forceinline__ void block_sum2(double &x, double &y) {
+    __shared__ double sx[QSV_BLOCK / 64], sy[QSV_BLOCK / 64];
+    x = wave_sum(x);
+    y = wave_sum(y);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sx[wave] = x;
+        sy[wave] = y;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        x = 0.0;
+        y = 0.0;
+        for (int i = 0; i < QSV_BLOCK / 64; ++i) {
+            x += sx[i];
+            y += sy[i];
+        }
+    }
+}
+
+// partials[2*block + s] = sum over this block's pairs of |eig_s[0] a0 + eig_s[1] a1|^2
+__global__ __launch_bounds__(QSV_BLOCK) void k_measure_probs(const amp_t *__restrict__ a, uint64_t pairs, int bit,
+                                                            cplx e00, cplx e01, cplx e10, cplx e11,
+                                                            double *__restrict__ partials) {
+    double p0 = 0.0, p1 = 0.0;
+    const uint64_t s = 1ull << bit;
+    for (uint64_t w = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; w < pairs;
+         w += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t i0 = insert_zero(w, bit);
+        const amp_t a0 = a[i0], a1 = a[i0 + s];
+        const amp_t r0 = cfma(e01, a1, cmul(e00, a0));
+        const amp_t r1 = cfma(e11, a1, cmul(e10, a0));
+        p0 += r0.x * r0.x + r0.y * r0.y;
+        p1 += r1.x * r1.x + r1.y * r1.y;
+    }
+    block_sum2(p0, p1);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = p0;
+        partials[2 * blockIdx.x + 1] = p1;
+    }
+}
+
+// out[w] = scale * (e0 a[i0] + e1 a[i1]): the (n-1)-qubit post-measurement ket.
+__global__ __launch_bounds__(QSV_BLOCK) void k_collapse(const amp_t *__restrict__ a, amp_t *__restrict__ out,
+                                                       uint64_t pairs, int bit, cplx e0, cplx e1, double scale) {
+    const uint64_t s = 1ull << bit;
+    for (uint64_t w = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; w < pairs;
+         w += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t i0 = insert_zero(w, bit);
+        amp_t r = cfma(e1, a[i0 + s], cmul(e0, a[i0]));
+        r.x *= scale;
+        r.y *= scale;
+        out[w] = r;
+    }
+}
+
+// out[j] = amp[bit(j)] * a[j with the bit removed]: kron(state, new) + move (gates.py:149-152).
+__global__ __launch_bounds__(QSV_BLOCK) void k_insert(const amp_t *__restrict__ a, amp_t *__restrict__ out,
+                                                     uint64_t out_amps, int bit, cplx c0, cplx c1) {
+    for (uint64_t j = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; j < out_amps;
+         j += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t low = j & ((1ull << bit) - 1ull);
+        const uint64_t src = ((j >> (bit + 1)) << bit) | low;
+        out[j] = cmul(((j >> bit) & 1ull) ? c1 : c0, a[src]);
+    }
+}
+
+struct PermArgs {
+    int32_t n;
+    uint8_t src_bit[64];  // bit j of the destination index comes from bit src_bit[j] of the source index
+};
+
+__global__ __launch_bounds__(QSV_BLOCK) void k_permute(const amp_t *__restrict__ a, amp_t *__restrict__ out,
+                                                      uint64_t amps, const PermArgs g) {
+    for (uint64_t j = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; j < amps;
+         j += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        uint64_t src = 0;
+        for (int b = 0; b < g.n; ++b) src |= ((j >> b) & 1ull) << g.src_bit[b];
+        out[j] = a[src];
+    }
+}
+
+__global__ __launch_bounds__(QSV_BLOCK) void k_norm2(const amp_t *__restrict__ a, uint64_t amps,
+                                                    double *__restrict__ partials) {
+    double s = 0.0, unused = 0.0;
+    for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < amps;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const amp_t v = a[i];
+        s += v.x * v.x + v.y * v.y;
+    }
+    block_sum2(s, unused);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = s;
+        partials[2 * blockIdx.x + 1] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(QSV_BLOCK) void k_inner(const amp_t *__restrict__ a, const amp_t *__restrict__ b,
+                                                    uint64_t amps, double *__restrict__ partials) {
+    double re = 0.0, im = 0.0;
+    for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < amps;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const amp_t x = a[i], y = b[i];
+        re += x.x * y.x + x.y * y.y;  // conj(x) * y
+        im += x.x * y.y - x.y * y.x;
+    }
+    block_sum2(re, im);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = re;
+        partials[2 * blockIdx.x + 1] = im;
+    }
+}
+
+__global__ void k_gather_prob(const amp_t *__restrict__ a, const uint64_t *__restrict__ idx, int count,
+                              double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        const amp_t v = a[idx[i]];
+        out[i] = v.x * v.x + v.y * v.y;
+    }
+}
+
+__global__ __launch_bounds__(QSV_BLOCK) void k_scale(amp_t *__restrict__ a, uint64_t amps, cplx c) {
+    for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < amps;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+        a[i] = cmul(c, a[i]);
+}
+
+__global__ __launch_bounds__(QSV_BLOCK) void k_zero(amp_t *__restrict__ a, uint64_t amps, uint64_t one_at) {
+    for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < amps;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+        a[i] = amp_t{i == one_at ? 1.0 : 0.0, 0.0};
+}
+
+// splitmix64: counter-based, so a sharded register can be filled shard by shard from global indices.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(QSV_BLOCK) void k_fill_random(amp_t *__restrict__ a, uint64_t amps, uint64_t seed,
+                                                          uint64_t index_offset, double *__restrict__ partials) {
+    double s = 0.0, unused = 0.0;
+    const uint64_t key = splitmix64(seed);
+    for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < amps;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t g = i + index_offset;
+        const uint64_t r1 = splitmix64(key ^ (2 * g)), r2 = splitmix64(key ^ (2 * g + 1));
+        const double u1 = (static_cast<double>(r1 >> 11) + 0.5) * 0x1.0p-53;  // (0, 1)
+        const double u2 = (static_cast<double>(r2 >> 11) + 0.5) * 0x1.0p-53;
+        const double rad = sqrt(-2.0 * log(u1));
+        double sn, cs;
+        sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+        const amp_t v = {rad * cs, rad * sn};
+        a[i] = v;
+        s += v.x * v.x + v.y * v.y;
+    }
+    block_sum2(s, unused);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = s;
+        partials[2 * blockIdx.x + 1] = 0.0;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// host-side helpers
+// ----------------------------------------------------------------------------------------------------
+int grid_for(uint64_t items, int per_block, int cap) {
+    uint64_t blocks = (items + per_block - 1) / per_block;
+    if (blocks < 1) blocks = 1;
+    if (cap > 0 && blocks > static_cast<uint64_t>(cap)) blocks = cap;
+    if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+    return static_cast<int>(blocks);
+}
+
+int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return qsv_fail(QSV_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return QSV_OK;
+}
+
+// Sum the first `blocks` pairs of partials on the host, in index order (deterministic).
+int sum_partials(qsv_state *st, int blocks, double *x, double *y) {
+    QSV_HIP(hipMemcpyAsync(st->partials_host, st->partials, sizeof(double) * 2 * blocks, hipMemcpyDeviceToHost,
+                           st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));
+    double sx = 0.0, sy = 0.0;
+    for (int i = 0; i < blocks; ++i) {
+        sx += st->partials_host[2 * i];
+        sy += st->partials_host[2 * i + 1];
+    }
+    *x = sx;
+    if (y) *y = sy;
+    return QSV_OK;
+}
+
+template <int KH, int KL, int U>
+void launch_dense_nt(qsv_state *st, const GateArgs &g, int grid) {
+    if (st->nontemporal)
+        hipLaunchKernelGGL((k_dense<KH, KL, U, true>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g);
+    else
+        hipLaunchKernelGGL((k_dense<KH, KL, U, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g);
+}
+
+template <int KH, int KL>
+int launch_dense(qsv_state *st, const GateArgs &g) {
+    int U = st->unroll > 0 ? st->unroll : (8 >> KH);  // 8 x 16-byte loads in flight per lane
+    // never more unrolling than there is work for one tile
+    while (U > 1 && g.W < static_cast<uint64_t>(QSV_BLOCK) * U) U >>= 1;
+    const int grid = grid_for(g.W, QSV_BLOCK * U, st->grid_cap);
+    switch (U) {
+        case 1: launch_dense_nt<KH, KL, 1>(st, g, grid); break;
+        case 2: launch_dense_nt<KH, KL, 2>(st, g, grid); break;
+        case 4: launch_dense_nt<KH, KL, 4>(st, g, grid); break;
+        default: launch_dense_nt<KH, KL, 8>(st, g, grid); break;
+    }
+    return check_launch();
+}
+
+int dispatch_dense(qsv_state *st, int KH, int KL, const GateArgs &g) {
+    if (KH == 1 && KL == 0) return launch_dense<1, 0>(st, g);
+    if (KH == 0 && KL == 1) return launch_dense<0, 1>(st, g);
+    if (KH == 2 && KL == 0) return launch_dense<2, 0>(st, g);
+    if (KH == 1 && KL == 1) return launch_dense<1, 1>(st, g);
+    if (KH == 0 && KL == 2) return launch_dense<0, 2>(st, g);
+    return qsv_fail(QSV_EINVAL, "dense kernel: unsupported target split");
+}
+
+// Fill pos/or_mask/lane_ctrl/W from target and control bit positions.
+template <class Args>
+int fill_enumeration(const qsv_state *st, Args &g, const std::vector<int> &removed_high, int nctrl,
+                     const int *cbits) {
+    std::vector<int> ins(removed_high);
+    g.or_mask = 0;
+    g.lane_ctrl = 0;
+    for (int i = 0; i < nctrl; ++i) {
+        if (cbits[i] >= QSV_LANE_BITS) {
+            ins.push_back(cbits[i]);
+            g.or_mask |= 1ull << cbits[i];
+        } else {
+            g.lane_ctrl |= 1u << cbits[i];
+        }
+    }
+    std::sort(ins.begin(), ins.end());
+    if (ins.size() > static_cast<size_t>(QSV_MAX_INS)) return qsv_fail(QSV_EINVAL, "too many controls");
+    g.nins = static_cast<int>(ins.size());
+    for (size_t i = 0; i < ins.size(); ++i) g.pos[i] = static_cast<uint8_t>(ins[i]);
+    g.W = st->amps >> ins.size();
+    return QSV_OK;
+}
+
+// Expand a controlled k-qubit matrix to the full (k + nctrl)-qubit matrix (controls as leading legs).
+std::vector<double> expand_controls(int k, int nctrl, const double *m) {
+    const int D = 1 << k, F = 1 << (k + nctrl);
+    std::vector<double> full(2ull * F * F, 0.0);
+    for (int r = 0; r < F; ++r) full[2 * (r * F + r)] = 1.0;
+    const int b0 = F - D;  // all controls = 1
+    for (int r = 0; r < D; ++r)
+        for (int c = 0; c < D; ++c) {
+            full[2 * ((b0 + r) * F + b0 + c)] = m[2 * (r * D + c)];
+            full[2 * ((b0 + r) * F + b0 + c) + 1] = m[2 * (r * D + c) + 1];
+        }
+    return full;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------------
+// launchers
+// ----------------------------------------------------------------------------------------------------
+int qsvk_ensure_matrix(qsv_state *st, size_t bytes) {
+    if (st->dev_matrix_bytes >= bytes) return QSV_OK;
+    if (st->dev_matrix) {
+        QSV_HIP(hipStreamSynchronize(st->stream));
+        QSV_HIP(hipFree(st->dev_matrix));
+        st->dev_matrix = nullptr;
+        st->dev_matrix_bytes = 0;
+    }
+    if (hipMalloc(reinterpret_cast<void **>(&st->dev_matrix), bytes) != hipSuccess)
+        return qsv_fail(QSV_ENOMEM, "device allocation of the gate-matrix buffer failed");
+    st->dev_matrix_bytes = bytes;
+    return QSV_OK;
+}
+
+int qsvk_scratch(qsv_state *st, uint64_t amps, amp_t **out) {
+    (void)st;
+    if (hipMalloc(reinterpret_cast<void **>(out), sizeof(amp_t) * (amps ? amps : 1)) != hipSuccess)
+        return qsv_fail(QSV_ENOMEM, "device allocation of a scratch register failed");
+    return QSV_OK;
+}
+
+int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user) {
+    if (k < 1 || k > QSV_MAX_K) return qsv_fail(QSV_EINVAL, "generic gate: k must be in 1..6");
+    const size_t bytes = sizeof(double) * 2ull << (2 * k);
+    int rc = qsvk_ensure_matrix(st, bytes);
+    if (rc) return rc;
+    QSV_HIP(hipMemcpyAsync(st->dev_matrix, m_user, bytes, hipMemcpyHostToDevice, st->stream));
+    GenericArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.K = k;
+    g.W = st->amps >> k;
+    std::vector<int> sorted(bits, bits + k);
+    std::sort(sorted.begin(), sorted.end());
+    for (int j = 0; j < k; ++j) {
+        g.sorted_pos[j] = static_cast<uint8_t>(sorted[j]);
+        g.leg_pos[j] = static_cast<uint8_t>(bits[j]);
+    }
+    const int grid = grid_for(g.W, QSV_BLOCK, 4096);
+    switch (k) {
+        case 1: hipLaunchKernelGGL((k_generic<1>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
+        case 2: hipLaunchKernelGGL((k_generic<2>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
+        case 3: hipLaunchKernelGGL((k_generic<3>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
+        case 4: hipLaunchKernelGGL((k_generic<4>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
+        case 5: hipLaunchKernelGGL((k_generic<5>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
+        default: hipLaunchKernelGGL((k_generic<6>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
+    }
+    return check_launch();
+}
+
+// bits[j] = bit position of matrix leg j (leg 0 most significant); k in {1, 2}.
+int qsvk_dense(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits, const double *m_user) {
+    if (k < 1 || k > 2) return qsv_fail(QSV_EINVAL, "dense kernel handles 1- and 2-qubit matrices");
+    if (st->n < QSV_LANE_BITS) {
+        // tiny register: fold the controls into a (k + nctrl)-qubit matrix for the gather kernel
+        if (nctrl == 0) return qsvk_generic(st, k, bits, m_user);
+        std::vector<int> legs(cbits, cbits + nctrl);
+        legs.insert(legs.end(), bits, bits + k);
+        const std::vector<double> full = expand_controls(k, nctrl, m_user);
+        return qsvk_generic(st, k + nctrl, legs.data(), full.data());
+    }
+    GateArgs g;
+    std::memset(&g, 0, sizeof(g));
+    std::vector<int> high, low;
+    for (int j = 0; j < k; ++j) (bits[j] >= QSV_LANE_BITS ? high : low).push_back(bits[j]);
+    const int KH = static_cast<int>(high.size()), KL = static_cast<int>(low.size());
+    int rc = fill_enumeration(st, g, high, nctrl, cbits);
+    if (rc) return rc;
+    for (int h = 0; h < (1 << KH); ++h) {
+        uint64_t o = 0;
+        for (int i = 0; i < KH; ++i)
+            if ((h >> i) & 1) o |= 1ull << high[i];
+        g.hoff[h] = o;
+    }
+    for (int j = 0; j < KL; ++j) g.lbit[j] = low[j];
+    for (int x = 0; x < (1 << KL); ++x) {
+        int mask = 0;
+        for (int j = 0; j < KL; ++j)
+            if ((x >> j) & 1) mask |= 1 << low[j];
+        g.lxor[x] = mask;
+    }
+    // kernel order: index = (h << KL) | l, h bit i <-> high[i], l bit i <-> low[i]
+    const int D = 1 << k;
+    auto user_index = [&](int kidx) {
+        const int h = kidx >> KL, l = kidx & ((1 << KL) - 1);
+        int u = 0;
+        for (int j = 0; j < k; ++j) {
+            int bitval = 0;
+            for (int i = 0; i < KH; ++i)
+                if (high[i] == bits[j]) bitval = (h >> i) & 1;
+            for (int i = 0; i < KL; ++i)
+                if (low[i] == bits[j]) bitval = (l >> i) & 1;
+            u |= bitval << (k - 1 - j);
+        }
+        return u;
+    };
+    for (int r = 0; r < D; ++r)
+        for (int c = 0; c < D; ++c) {
+            const int ur = user_index(r), uc = user_index(c);
+            g.m[2 * (r * D + c)] = m_user[2 * (ur * D + uc)];
+            g.m[2 * (r * D + c) + 1] = m_user[2 * (ur * D + uc) + 1];
+        }
+    return dispatch_dense(st, KH, KL, g);
+}
+
+// SWAP of two bits >= QSV_LANE_BITS: exchange a[base | Sa] <-> a[base | Sb]; the 00 and 11 quarters stay put.
+int qsvk_pair_exchange(qsv_state *st, int bit_a, int bit_b) {
+    GateArgs g;
+    std::memset(&g, 0, sizeof(g));
+    std::vector<int> removed = {bit_a, bit_b};
+    int rc = fill_enumeration(st, g, removed, 0, nullptr);
+    if (rc) return rc;
+    g.hoff[0] = 1ull << bit_a;
+    g.hoff[1] = 1ull << bit_b;
+    const double x[8] = {0, 0, 1, 0, 1, 0, 0, 0};
+    std::memcpy(g.m, x, sizeof(x));
+    return dispatch_dense(st, 1, 0, g);
+}
+
+// bits[j] = position of diagonal leg j (leg 0 most significant); d has 2^k complex entries.
+int qsvk_diag(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits, const double *d_user) {
+    if (k < 1 || k > QSV_MAX_K) return qsv_fail(QSV_EINVAL, "diagonal gate: k must be in 1..6");
+    if (k <= 2 && st->n >= QSV_LANE_BITS) {
+        DiagArgs g;
+        std::memset(&g, 0, sizeof(g));
+        int rc = fill_enumeration(st, g, {}, nctrl, cbits);
+        if (rc) return rc;
+        g.b0 = bits[0];
+        g.b1 = k == 2 ? bits[1] : -1;
+        std::memcpy(g.d, d_user, sizeof(double) * (2 << k));
+        int U = st->unroll > 0 ? st->unroll : 8;
+        while (U > 1 && g.W < static_cast<uint64_t>(QSV_BLOCK) * U) U >>= 1;
+        const int grid = grid_for(g.W, QSV_BLOCK * U, st->grid_cap);
+#define QSV_LAUNCH_DIAG(UU)                                                                                       \
+    if (st->nontemporal)                                                                                          \
+        hipLaunchKernelGGL((k_diag<UU, true>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g);           \
+    else                                                                                                          \
+        hipLaunchKernelGGL((k_diag<UU, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g)
+        switch (U) {
+            case 1: QSV_LAUNCH_DIAG(1); break;
+            case 2: QSV_LAUNCH_DIAG(2); break;
+            case 4: QSV_LAUNCH_DIAG(4); break;
+            default: QSV_LAUNCH_DIAG(8); break;
+        }
+#undef QSV_LAUNCH_DIAG
+        return check_launch();
+    }
+    // table path (k > 2 or tiny register); controls are folded into the table
+    std::vector<int> legs(cbits, cbits + nctrl);
+    legs.insert(legs.end(), bits, bits + k);
+    const int K = k + nctrl;
+    if (K > QSV_MAX_K) return qsv_fail(QSV_EINVAL, "diagonal gate: too many legs for the table kernel");
+    std::vector<double> table(2ull << K, 0.0);
+    for (int i = 0; i < (1 << K); ++i) {
+        table[2 * i] = 1.0;
+        if ((i >> k) == (1 << nctrl) - 1) {
+            table[2 * i] = d_user[2 * (i & ((1 << k) - 1))];
+            table[2 * i + 1] = d_user[2 * (i & ((1 << k) - 1)) + 1];
+        }
+    }
+    const size_t tbytes = sizeof(double) * table.size();
+    int rc = qsvk_ensure_matrix(st, tbytes + 64);
+    if (rc) return rc;
+    uint8_t pos[8] = {0};
+    for (int j = 0; j < K; ++j) pos[j] = static_cast<uint8_t>(legs[j]);
+    QSV_HIP(hipMemcpyAsync(st->dev_matrix, table.data(), tbytes, hipMemcpyHostToDevice, st->stream));
+    uint8_t *dpos = reinterpret_cast<uint8_t *>(st->dev_matrix) + tbytes;
+    QSV_HIP(hipMemcpyAsync(dpos, pos, 8, hipMemcpyHostToDevice, st->stream));
+    // the two pageable-source copies above are staged before return (HIP semantics), so `table` may die
+    QSV_HIP(hipStreamSynchronize(st->stream));
+    const int grid = grid_for(st->amps, QSV_BLOCK, 4096);
+    hipLaunchKernelGGL(k_diag_table, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, K, dpos,
+                       st->dev_matrix);
+    return check_launch();
+}
+
+int qsvk_phase(qsv_state *st, int nctrl, const int *cbits, double re, double im) {
+    if (st->n < QSV_LANE_BITS || nctrl == 0) {
+        if (nctrl == 0) return qsvk_scale(st, re, im);
+        if (nctrl > QSV_MAX_K) return qsv_fail(QSV_EINVAL, "phase on a tiny register: too many qubits");
+        // all qubits are "controls": table with the phase at the all-ones entry
+        std::vector<double> d = {1.0, 0.0, re, im};
+        return qsvk_diag(st, 1, cbits + nctrl - 1, nctrl - 1, cbits, d.data());
+    }
+    DiagArgs g;
+    std::memset(&g, 0, sizeof(g));
+    int rc = fill_enumeration(st, g, {}, nctrl, cbits);
+    if (rc) return rc;
+    // every enumerated amplitude already has all controls = 1: multiply by the phase whatever bit b0 is
+    g.b0 = 0;
+    g.b1 = -1;
+    g.d[0] = g.d[2] = re;
+    g.d[1] = g.d[3] = im;
+    int U = st->unroll > 0 ? st->unroll : 8;
+    while (U > 1 && g.W < static_cast<uint64_t>(QSV_BLOCK) * U) U >>= 1;
+    const int grid = grid_for(g.W, QSV_BLOCK * U, st->grid_cap);
+    switch (U) {
+        case 1: hipLaunchKernelGGL((k_diag<1, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g); break;
+        case 2: hipLaunchKernelGGL((k_diag<2, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g); break;
+        case 4: hipLaunchKernelGGL((k_diag<4, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g); break;
+        default: hipLaunchKernelGGL((k_diag<8, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g); break;
+    }
+    return check_launch();
+}
+
+int qsvk_measure_probs(qsv_state *st, int bit, const double e0[4], const double e1[4], double *p0, double *p1) {
+    const uint64_t pairs = st->amps >> 1;
+    const int grid = grid_for(pairs, QSV_BLOCK * 8, QSV_REDUCE_BLOCKS);
+    hipLaunchKernelGGL(k_measure_probs, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, pairs, bit,
+                       cplx{e0[0], e0[1]}, cplx{e0[2], e0[3]}, cplx{e1[0], e1[1]}, cplx{e1[2], e1[3]},
+                       st->partials);
+    int rc = check_launch();
+    if (rc) return rc;
+    return sum_partials(st, grid, p0, p1);
+}
+
+// Replace the register by `fresh` (holding new_amps amplitudes): adopt it when the library owns the
+// memory, copy back when the caller does (the view pointer must stay valid).
+static int adopt(qsv_state *st, amp_t *fresh, uint64_t new_amps) {
+    if (st->owns_data) {
+        QSV_HIP(hipStreamSynchronize(st->stream));
+        QSV_HIP(hipFree(st->data));
+        st->data = fresh;
+        st->capacity = new_amps;
+    } else {
+        QSV_HIP(hipMemcpyAsync(st->data, fresh, sizeof(amp_t) * new_amps, hipMemcpyDeviceToDevice, st->stream));
+        QSV_HIP(hipStreamSynchronize(st->stream));
+        QSV_HIP(hipFree(fresh));
+    }
+    st->amps = new_amps;
+    return QSV_OK;
+}
+
+int qsvk_collapse(qsv_state *st, int bit, const double e[4], double scale) {
+    const uint64_t pairs = st->amps >> 1;
+    amp_t *fresh = nullptr;
+    int rc = qsvk_scratch(st, pairs, &fresh);
+    if (rc) return rc;
+    const int grid = grid_for(pairs, QSV_BLOCK * 4, 8192);
+    hipLaunchKernelGGL(k_collapse, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, pairs, bit,
+                       cplx{e[0], e[1]}, cplx{e[2], e[3]}, scale);
+    rc = check_launch();
+    if (rc) {
+        (void)hipFree(fresh);
+        return rc;
+    }
+    st->n -= 1;
+    return adopt(st, fresh, pairs);
+}
+
+int qsvk_insert(qsv_state *st, int bit, const double amp[4]) {
+    const uint64_t out_amps = st->amps << 1;
+    if (!st->owns_data && out_amps > st->capacity)
+        return qsv_fail(QSV_ENOMEM, "insert: the caller-owned buffer has no room for one more qubit");
+    amp_t *fresh = nullptr;
+    int rc = qsvk_scratch(st, out_amps, &fresh);
+    if (rc) return rc;
+    const int grid = grid_for(out_amps, QSV_BLOCK * 4, 8192);
+    hipLaunchKernelGGL(k_insert, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, out_amps, bit,
+                       cplx{amp[0], amp[1]}, cplx{amp[2], amp[3]});
+    rc = check_launch();
+    if (rc) {
+        (void)hipFree(fresh);
+        return rc;
+    }
+    st->n += 1;
+    return adopt(st, fresh, out_amps);
+}
+
+int qsvk_permute(qsv_state *st, const int *src_bit_of_dst_bit) {
+    PermArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.n = st->n;
+    for (int b = 0; b < st->n; ++b) g.src_bit[b] = static_cast<uint8_t>(src_bit_of_dst_bit[b]);
+    amp_t *fresh = nullptr;
+    int rc = qsvk_scratch(st, st->amps, &fresh);
+    if (rc) return rc;
+    const int grid = grid_for(st->amps, QSV_BLOCK * 4, 8192);
+    hipLaunchKernelGGL(k_permute, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, st->amps, g);
+    rc = check_launch();
+    if (rc) {
+        (void)hipFree(fresh);
+        return rc;
+    }
+    return adopt(st, fresh, st->amps);
+}
+
+int qsvk_norm2(qsv_state *st, double *out) {
+    const int grid = grid_for(st->amps, QSV_BLOCK * 8, QSV_REDUCE_BLOCKS);
+    hipLaunchKernelGGL(k_norm2, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, st->partials);
+    int rc = check_launch();
+    if (rc) return rc;
+    return sum_partials(st, grid, out, nullptr);
+}
+
+int qsvk_inner(qsv_state *a, qsv_state *b, double *re, double *im) {
+    QSV_HIP(hipStreamSynchronize(b->stream));
+    const int grid = grid_for(a->amps, QSV_BLOCK * 8, QSV_REDUCE_BLOCKS);
+    hipLaunchKernelGGL(k_inner, dim3(grid), dim3(QSV_BLOCK), 0, a->stream, a->data, b->data, a->amps, a->partials);
+    int rc = check_launch();
+    if (rc) return rc;
+    return sum_partials(a, grid, re, im);
+}
+
+int qsvk_probabilities(qsv_state *st, const uint64_t *indices, int count, double *out) {
+    if (count <= 0) return QSV_OK;
+    const size_t ibytes = sizeof(uint64_t) * count, obytes = sizeof(double) * count;
+    int rc = qsvk_ensure_matrix(st, ibytes + obytes);
+    if (rc) return rc;
+    uint64_t *didx = reinterpret_cast<uint64_t *>(st->dev_matrix);
+    double *dout = reinterpret_cast<double *>(reinterpret_cast<char *>(st->dev_matrix) + ibytes);
+    QSV_HIP(hipMemcpyAsync(didx, indices, ibytes, hipMemcpyHostToDevice, st->stream));
+    hipLaunchKernelGGL(k_gather_prob, dim3((count + 255) / 256), dim3(256), 0, st->stream, st->data, didx, count,
+                       dout);
+    rc = check_launch();
+    if (rc) return rc;
+    QSV_HIP(hipMemcpyAsync(out, dout, obytes, hipMemcpyDeviceToHost, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));
+    return QSV_OK;
+}
+
+int qsvk_fill_random(qsv_state *st, uint64_t seed, uint64_t index_offset, double *norm2) {
+    const int grid = grid_for(st->amps, QSV_BLOCK * 8, QSV_REDUCE_BLOCKS);
+    hipLaunchKernelGGL(k_fill_random, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, seed,
+                       index_offset, st->partials);
+    int rc = check_launch();
+    if (rc) return rc;
+    double s = 0.0;
+    rc = sum_partials(st, grid, &s, nullptr);
+    if (norm2) *norm2 = s;
+    return rc;
+}
+
+int qsvk_scale(qsv_state *st, double re, double im) {
+    const int grid = grid_for(st->amps, QSV_BLOCK * 8, 8192);
+    hipLaunchKernelGGL(k_scale, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, cplx{re, im});
+    return check_launch();
+}
+
+int qsvk_set_basis(qsv_state *st, uint64_t index) {
+    const int grid = grid_for(st->amps, QSV_BLOCK * 8, 8192);
+    hipLaunchKernelGGL(k_zero, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, index);
+    return check_launch();
+}

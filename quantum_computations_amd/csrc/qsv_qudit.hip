@@ -1,0 +1,278 @@
+// d-level mode kernels of libqsv.so (gfx950): apply a d x d (or d^2 x d^2) operator along the mode axes of a
+// dense register viewed as (L, d, R) -- the np.tensordot(M, T, [1, axis]) + moveaxis contraction the reference's
+// cv_simulator performs on every MPS site (simulators/cv_simulator/utils.py:15,37; gates.py:73,160,222,246).
+//
+// Mode 0 is the most significant (slowest) axis, like qubit 0 of the qubit registers.
+
+#include "qsv_internal.h"
+
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct cplx {
+    double re, im;
+};
+
+__device__ __forceinline__ amp_t cmul(cplx m, amp_t a) {
+    return amp_t{m.re * a.x - m.im * a.y, m.re * a.y + m.im * a.x};
+}
+
+__device__ __forceinline__ amp_t cfma(cplx m, amp_t a, amp_t acc) {
+    return amp_t{fma(m.re, a.x, fma(-m.im, a.y, acc.x)), fma(m.re, a.y, fma(m.im, a.x, acc.y))};
+}
+
+// ----------------------------------------------------------------------------------------------------
+// out[l, i, r] = sum_j M[i, j] in[l, j, r]   (L, d_in, R) -> (L, d_out, R)
+//
+// A workgroup owns a tile of TR consecutive r values of one l: the (d_in x TR) input tile is staged in LDS
+// with fully coalesced loads (TR * 16 B contiguous per row), then every wave produces output rows
+// i = wave, wave + 4, ...  four at a time, so each LDS read feeds four complex FMAs.  M is read with
+// wave-uniform addresses (scalar loads, served by the scalar cache / L2).
+// ----------------------------------------------------------------------------------------------------
+constexpr int TR = 64;      // r values per tile = one wave-width
+constexpr int ROWS = 4;     // output rows per wave per pass
+
+__global__ __launch_bounds__(QSV_BLOCK) void k_axis_tile(const amp_t *__restrict__ in, amp_t *__restrict__ out,
+                                                        uint64_t L, int d_in, int d_out, uint64_t R,
+                                                        uint64_t r_tiles, const double *__restrict__ M) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    amp_t *tile = reinterpret_cast<amp_t *>(smem_raw);  // [d_in][TR]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t total = L * r_tiles;
+    for (uint64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const uint64_t l = t / r_tiles, r0 = (t % r_tiles) * TR;
+        const bool r_ok = r0 + lane < R;
+        __syncthreads();  // previous tile fully consumed
+        for (int j = wave; j < d_in; j += QSV_BLOCK / 64)
+            tile[j * TR + lane] = r_ok ? in[(l * d_in + j) * R + r0 + lane] : amp_t{0.0, 0.0};
+        __syncthreads();
+        for (int i0 = wave * ROWS; i0 < d_out; i0 += (QSV_BLOCK / 64) * ROWS) {
+            amp_t acc[ROWS];
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) acc[k] = amp_t{0.0, 0.0};
+            for (int j = 0; j < d_in; ++j) {
+                const amp_t x = tile[j * TR + lane];
+#pragma unroll
+                for (int k = 0; k < ROWS; ++k) {
+                    const int i = min(i0 + k, d_out - 1);
+                    const cplx m = {M[2 * (static_cast<size_t>(i) * d_in + j)],
+                                    M[2 * (static_cast<size_t>(i) * d_in + j) + 1]};
+                    acc[k] = cfma(m, x, acc[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k)
+                if (i0 + k < d_out && r_ok) out[(l * d_out + i0 + k) * R + r0 + lane] = acc[k];
+        }
+    }
+}
+
+// Small-R case (the mode is the last or a late axis: fibres are short contiguous runs).  One thread per
+// output element, inputs re-read through the caches.  Correct for every shape; used when R < TR.
+__global__ __launch_bounds__(QSV_BLOCK) void k_axis_simple(const amp_t *__restrict__ in, amp_t *__restrict__ out,
+                                                          uint64_t L, int d_in, int d_out, uint64_t R,
+                                                          const double *__restrict__ M) {
+    const uint64_t total = L * d_out * R;
+    for (uint64_t o = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t r = o % R, i = (o / R) % d_out, l = o / (R * d_out);
+        amp_t acc = {0.0, 0.0};
+        for (int j = 0; j < d_in; ++j) {
+            const cplx m = {M[2 * (i * d_in + j)], M[2 * (i * d_in + j) + 1]};
+            acc = cfma(m, in[(l * d_in + j) * R + r], acc);
+        }
+        out[o] = acc;
+    }
+}
+
+// in[l, j, r] *= diag[j]
+__global__ __launch_bounds__(QSV_BLOCK) void k_axis_diag(amp_t *__restrict__ a, uint64_t total, int d, uint64_t R,
+                                                        const double *__restrict__ diag) {
+    for (uint64_t o = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t j = (o / R) % d;
+        a[o] = cmul(cplx{diag[2 * j], diag[2 * j + 1]}, a[o]);
+    }
+}
+
+// Two-mode dense: view (L, d, Mid, d, R); out[l,i0,m,i1,r] = sum_{j0,j1} G[(i0,i1),(j0,j1)] in[l,j0,m,j1,r].
+__global__ __launch_bounds__(QSV_BLOCK) void k_mode2_simple(const amp_t *__restrict__ in, amp_t *__restrict__ out,
+                                                           uint64_t L, int d, uint64_t Mid, uint64_t R,
+                                                           const double *__restrict__ G) {
+    const uint64_t total = L * d * Mid * d * R;
+    const uint64_t s1 = R, sm = R * d, s0 = R * d * Mid, sl = R * d * Mid * d;
+    const int d2 = d * d;
+    for (uint64_t o = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t r = o % R, i1 = (o / s1) % d, m = (o / sm) % Mid, i0 = (o / s0) % d, l = o / sl;
+        const uint64_t base = l * sl + m * sm + r;
+        const size_t row = (i0 * d + i1) * static_cast<size_t>(d2);
+        amp_t acc = {0.0, 0.0};
+        for (int j0 = 0; j0 < d; ++j0)
+            for (int j1 = 0; j1 < d; ++j1) {
+                const cplx g = {G[2 * (row + j0 * d + j1)], G[2 * (row + j0 * d + j1) + 1]};
+                acc = cfma(g, in[base + j0 * s0 + j1 * s1], acc);
+            }
+        out[o] = acc;
+    }
+}
+
+__global__ __launch_bounds__(QSV_BLOCK) void k_mode2_diag(amp_t *__restrict__ a, uint64_t total, int d, uint64_t Mid,
+                                                         uint64_t R, const double *__restrict__ diag) {
+    const uint64_t s1 = R, s0 = R * d * Mid;
+    for (uint64_t o = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t i1 = (o / s1) % d, i0 = (o / s0) % d;
+        const uint64_t k = i0 * d + i1;
+        a[o] = cmul(cplx{diag[2 * k], diag[2 * k + 1]}, a[o]);
+    }
+}
+
+int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return qsv_fail(QSV_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return QSV_OK;
+}
+
+uint64_t ipow(uint64_t b, int e) {
+    uint64_t r = 1;
+    while (e-- > 0) r *= b;
+    return r;
+}
+
+int grid_of(uint64_t items, int per_block, int cap) {
+    uint64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > static_cast<uint64_t>(cap)) b = cap;
+    return static_cast<int>(b);
+}
+
+int launch_axis(hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in, uint64_t d_out,
+                uint64_t R, const double *dev_m) {
+    const size_t lds = sizeof(amp_t) * d_in * TR;
+    if (R >= TR && lds <= 160 * 1024 - 256) {
+        const uint64_t r_tiles = (R + TR - 1) / TR;
+        const int grid = grid_of(L * r_tiles, 1, 1 << 20);
+        if (lds > 64 * 1024)
+            QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_axis_tile),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        hipLaunchKernelGGL(k_axis_tile, dim3(grid), dim3(QSV_BLOCK), lds, stream, in, out, L, static_cast<int>(d_in),
+                           static_cast<int>(d_out), R, r_tiles, dev_m);
+    } else {
+        const int grid = grid_of(L * d_out * R, QSV_BLOCK, 1 << 16);
+        hipLaunchKernelGGL(k_axis_simple, dim3(grid), dim3(QSV_BLOCK), 0, stream, in, out, L,
+                           static_cast<int>(d_in), static_cast<int>(d_out), R, dev_m);
+    }
+    return check_launch();
+}
+
+// Replace the register by `fresh` (see qsv_kernels.hip::adopt).
+int adopt(qsv_state *st, amp_t *fresh) {
+    if (st->owns_data) {
+        QSV_HIP(hipStreamSynchronize(st->stream));
+        QSV_HIP(hipFree(st->data));
+        st->data = fresh;
+    } else {
+        QSV_HIP(hipMemcpyAsync(st->data, fresh, sizeof(amp_t) * st->amps, hipMemcpyDeviceToDevice, st->stream));
+        QSV_HIP(hipStreamSynchronize(st->stream));
+        QSV_HIP(hipFree(fresh));
+    }
+    return QSV_OK;
+}
+
+}  // namespace
+
+int qsvq_mode1(qsv_state *st, int mode, const double *m, bool diag) {
+    const uint64_t d = st->d, R = ipow(d, st->n - 1 - mode), L = ipow(d, mode);
+    const size_t bytes = sizeof(double) * 2 * (diag ? d : d * d);
+    int rc = qsvk_ensure_matrix(st, bytes);
+    if (rc) return rc;
+    QSV_HIP(hipMemcpyAsync(st->dev_matrix, m, bytes, hipMemcpyHostToDevice, st->stream));
+    if (diag) {
+        const int grid = grid_of(st->amps, QSV_BLOCK * 4, 1 << 16);
+        hipLaunchKernelGGL(k_axis_diag, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps,
+                           static_cast<int>(d), R, st->dev_matrix);
+        return check_launch();
+    }
+    amp_t *fresh = nullptr;
+    rc = qsvk_scratch(st, st->amps, &fresh);
+    if (rc) return rc;
+    rc = launch_axis(st->stream, st->data, fresh, L, d, d, R, st->dev_matrix);
+    if (rc) {
+        (void)hipFree(fresh);
+        return rc;
+    }
+    return adopt(st, fresh);
+}
+
+int qsvq_mode2(qsv_state *st, int mode0, int mode1, const double *m, bool diag) {
+    // G is given for legs (mode0, mode1); the kernels want (earlier axis, later axis)
+    const uint64_t d = st->d, d2 = d * d;
+    const int a = mode0 < mode1 ? mode0 : mode1, b = mode0 < mode1 ? mode1 : mode0;
+    const uint64_t L = ipow(d, a), Mid = ipow(d, b - a - 1), R = ipow(d, st->n - 1 - b);
+    std::vector<double> g;
+    const double *src = m;
+    if (mode0 > mode1) {  // transpose the two legs on rows and columns (or on the diagonal)
+        if (diag) {
+            g.resize(2 * d2);
+            for (uint64_t i0 = 0; i0 < d; ++i0)
+                for (uint64_t i1 = 0; i1 < d; ++i1) {
+                    g[2 * (i1 * d + i0)] = m[2 * (i0 * d + i1)];
+                    g[2 * (i1 * d + i0) + 1] = m[2 * (i0 * d + i1) + 1];
+                }
+        } else {
+            g.resize(2 * d2 * d2);
+            for (uint64_t i0 = 0; i0 < d; ++i0)
+                for (uint64_t i1 = 0; i1 < d; ++i1)
+                    for (uint64_t j0 = 0; j0 < d; ++j0)
+                        for (uint64_t j1 = 0; j1 < d; ++j1) {
+                            const uint64_t dst = (i1 * d + i0) * d2 + (j1 * d + j0);
+                            const uint64_t s = (i0 * d + i1) * d2 + (j0 * d + j1);
+                            g[2 * dst] = m[2 * s];
+                            g[2 * dst + 1] = m[2 * s + 1];
+                        }
+        }
+        src = g.data();
+    }
+    const size_t bytes = sizeof(double) * 2 * (diag ? d2 : d2 * d2);
+    int rc = qsvk_ensure_matrix(st, bytes);
+    if (rc) return rc;
+    QSV_HIP(hipMemcpyAsync(st->dev_matrix, src, bytes, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));  // `g` dies at return
+    if (diag) {
+        const int grid = grid_of(st->amps, QSV_BLOCK * 4, 1 << 16);
+        hipLaunchKernelGGL(k_mode2_diag, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps,
+                           static_cast<int>(d), Mid, R, st->dev_matrix);
+        return check_launch();
+    }
+    amp_t *fresh = nullptr;
+    rc = qsvk_scratch(st, st->amps, &fresh);
+    if (rc) return rc;
+    const int grid = grid_of(st->amps, QSV_BLOCK, 1 << 16);
+    hipLaunchKernelGGL(k_mode2_simple, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, L,
+                       static_cast<int>(d), Mid, R, st->dev_matrix);
+    rc = check_launch();
+    if (rc) {
+        (void)hipFree(fresh);
+        return rc;
+    }
+    return adopt(st, fresh);
+}
+
+int qsvq_tensor_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in,
+                     uint64_t d_out, uint64_t R, const double *m_host) {
+    QSV_HIP(hipSetDevice(device));
+    double *dev_m = nullptr;
+    const size_t bytes = sizeof(double) * 2 * d_in * d_out;
+    if (hipMalloc(reinterpret_cast<void **>(&dev_m), bytes) != hipSuccess)
+        return qsv_fail(QSV_ENOMEM, "device allocation of the operator failed");
+    hipError_t e = hipMemcpyAsync(dev_m, m_host, bytes, hipMemcpyHostToDevice, stream);
+    int rc = e == hipSuccess ? launch_axis(stream, in, out, L, d_in, d_out, R, dev_m)
+                             : qsv_fail(QSV_EHIP, std::string("operator upload: ") + hipGetErrorString(e));
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(dev_m);
+    return rc;
+}

@@ -1,0 +1,342 @@
+"""Device-resident registers: thin Python handles over ``qsv_state`` (include/qsv.h).
+
+``DeviceState`` is what ``Gate.apply`` receives when the caller wants the register to stay in HBM between gates
+(the reference passes a NumPy ket to every ``apply`` -- ``simulators/dv_simulator/simulator.py:47`` -- which
+would cost one upload and one download per gate here).  Host arrays are only touched by ``from_numpy`` /
+``to_numpy``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _cbuf(a, n_complex: int | None = None) -> np.ndarray:
+    """Contiguous complex128 copy of ``a`` (the interleaved layout the C ABI wants)."""
+    arr = np.ascontiguousarray(np.asarray(a), dtype=np.complex128)
+    if n_complex is not None and arr.size != n_complex:
+        raise ValueError(f"expected {n_complex} complex entries, got {arr.size}")
+    return arr
+
+
+def _ptr(arr: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(arr.ctypes.data)
+
+
+def _ints(values) -> "C.Array[C.c_int]":
+    values = [int(v) for v in values]
+    return (C.c_int * max(len(values), 1))(*values)
+
+
+class DeviceState:
+    """An n-qubit complex128 register in HBM (qubit 0 = most significant bit, as in the reference)."""
+
+    def __init__(self, handle: C.c_void_p, keepalive=None):
+        self._h = handle
+        self._keepalive = keepalive   # e.g. the torch tensor backing a view
+
+    # ---- construction -------------------------------------------------------------------------
+    @classmethod
+    def zeros(cls, n_qubits: int, device: int = 0) -> "DeviceState":
+        """|0...0> on ``device`` (``n_qubits = 0`` is the empty register ``[1.]``, simulator.py:22)."""
+        h = C.c_void_p()
+        _lib.call("qsv_create", int(n_qubits), int(device), C.byref(h))
+        return cls(h)
+
+    @classmethod
+    def from_numpy(cls, ket: np.ndarray, device: int = 0) -> "DeviceState":
+        ket = np.asarray(ket)
+        if ket.ndim != 1:
+            raise ValueError("State has wrong dimensions.")
+        size = ket.shape[0]
+        if size == 0 or size & (size - 1):
+            raise ValueError("Given array is not a qubit state nor operator")
+        st = cls.zeros(size.bit_length() - 1, device)
+        buf = _cbuf(ket)
+        _lib.call("qsv_upload", st._h, _ptr(buf), 0, size)
+        return st
+
+    @classmethod
+    def view(cls, n_qubits: int, dev_ptr: int, capacity_amps: int, device: int = 0, stream: int = 0,
+             keepalive=None) -> "DeviceState":
+        """Wrap caller-owned device memory (e.g. ``tensor.data_ptr()``) without copying."""
+        h = C.c_void_p()
+        _lib.call("qsv_create_view", int(n_qubits), int(device), C.c_void_p(dev_ptr), int(capacity_amps),
+                  C.c_void_p(stream), C.byref(h))
+        return cls(h, keepalive)
+
+    @classmethod
+    def random(cls, n_qubits: int, seed: int, device: int = 0) -> "DeviceState":
+        """Normalised pseudo-random ket generated on the device (counter-based, reproducible)."""
+        st = cls.zeros(n_qubits, device)
+        st.fill_random(seed)
+        return st
+
+    def fill_random(self, seed: int, index_offset: int = 0, normalise: bool = True) -> float:
+        n2 = C.c_double()
+        _lib.call("qsv_fill_random", self._h, int(seed), int(index_offset), C.byref(n2))
+        if normalise:
+            _lib.call("qsv_scale", self._h, 1.0 / np.sqrt(n2.value), 0.0)
+        return n2.value
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            _lib.load().qsv_destroy(self._h)
+        self._h = None
+        self._keepalive = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inspection ---------------------------------------------------------------------------
+    @property
+    def num_qubits(self) -> int:
+        n = C.c_int()
+        _lib.call("qsv_num_qubits", self._h, C.byref(n))
+        return n.value
+
+    @property
+    def num_amps(self) -> int:
+        n = C.c_uint64()
+        _lib.call("qsv_num_amps", self._h, C.byref(n))
+        return n.value
+
+    @property
+    def shape(self) -> tuple[int]:
+        return (self.num_amps,)
+
+    ndim = 1
+
+    @property
+    def device_ptr(self) -> int:
+        p = C.c_void_p()
+        _lib.call("qsv_device_ptr", self._h, C.byref(p))
+        return p.value or 0
+
+    def to_numpy(self) -> np.ndarray:
+        out = np.empty(self.num_amps, dtype=np.complex128)
+        _lib.call("qsv_download", self._h, _ptr(out), 0, out.size)
+        return out
+
+    def download(self, offset: int, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=np.complex128)
+        _lib.call("qsv_download", self._h, _ptr(out), int(offset), int(count))
+        return out
+
+    def upload(self, amplitudes: np.ndarray, offset: int = 0) -> None:
+        buf = _cbuf(amplitudes)
+        _lib.call("qsv_upload", self._h, _ptr(buf), int(offset), buf.size)
+
+    def copy(self) -> "DeviceState":
+        other = DeviceState.zeros(self.num_qubits)
+        _lib.call("qsv_copy", other._h, self._h)
+        return other
+
+    def sync(self) -> None:
+        _lib.call("qsv_sync", self._h)
+
+    def set_option(self, option: int, value: int) -> None:
+        _lib.call("qsv_set_option", self._h, int(option), int(value))
+
+    def set_stream(self, stream: int) -> None:
+        _lib.call("qsv_set_stream", self._h, C.c_void_p(stream))
+
+    def set_basis(self, index: int) -> None:
+        _lib.call("qsv_set_basis", self._h, int(index))
+
+    # ---- gates --------------------------------------------------------------------------------
+    def apply_matrix(self, matrix: np.ndarray, indices) -> "DeviceState":
+        """In-place ``U_full @ ket`` for a 2^k x 2^k matrix on qubits ``indices`` (``Gate.apply``)."""
+        indices = [int(i) for i in indices]
+        k = len(indices)
+        m = _cbuf(matrix, (1 << k) ** 2)
+        if k == 1:
+            _lib.call("qsv_apply_1q", self._h, indices[0], _ptr(m))
+        elif k == 2:
+            _lib.call("qsv_apply_2q", self._h, indices[0], indices[1], _ptr(m))
+        else:
+            _lib.call("qsv_apply_kq", self._h, k, _ints(indices), _ptr(m))
+        return self
+
+    def apply_diagonal(self, diagonal, indices) -> "DeviceState":
+        indices = [int(i) for i in indices]
+        d = _cbuf(diagonal, 1 << len(indices))
+        if len(indices) == 1:
+            _lib.call("qsv_apply_diag_1q", self._h, indices[0], _ptr(d))
+        elif len(indices) == 2:
+            _lib.call("qsv_apply_diag_2q", self._h, indices[0], indices[1], _ptr(d))
+        else:
+            _lib.call("qsv_apply_kq", self._h, len(indices), _ints(indices), _ptr(_cbuf(np.diag(d))))
+        return self
+
+    def apply_cx(self, control: int, target: int) -> "DeviceState":
+        _lib.call("qsv_apply_cx", self._h, int(control), int(target))
+        return self
+
+    def apply_swap(self, q0: int, q1: int) -> "DeviceState":
+        _lib.call("qsv_apply_swap", self._h, int(q0), int(q1))
+        return self
+
+    def apply_controlled(self, matrix, controls, target: int) -> "DeviceState":
+        m = _cbuf(matrix, 4)
+        controls = list(controls)
+        _lib.call("qsv_apply_controlled_1q", self._h, len(controls), _ints(controls), int(target), _ptr(m))
+        return self
+
+    def apply_mcphase(self, qubits, phase: complex) -> "DeviceState":
+        qubits = list(qubits)
+        phase = complex(phase)
+        _lib.call("qsv_apply_mcphase", self._h, len(qubits), _ints(qubits), phase.real, phase.imag)
+        return self
+
+    def permute(self, new_ordering) -> "DeviceState":
+        _lib.call("qsv_permute", self._h, _ints(new_ordering))
+        return self
+
+    # ---- measurement / insertion --------------------------------------------------------------
+    def measure(self, index: int, eig0, eig1, forced: int | None = None, u01: float = 0.0):
+        """Collapse qubit ``index`` (register shrinks by one).  Returns ``(outcome, p0, p1)``."""
+        e0, e1 = _cbuf(eig0, 2), _cbuf(eig1, 2)
+        out, p0, p1 = C.c_int(), C.c_double(), C.c_double()
+        _lib.call("qsv_measure", self._h, int(index), _ptr(e0), _ptr(e1), -1 if forced is None else int(forced),
+                  float(u01), C.byref(out), C.byref(p0), C.byref(p1))
+        return out.value, p0.value, p1.value
+
+    def measure_probs(self, index: int, eig0, eig1) -> tuple[float, float]:
+        e0, e1 = _cbuf(eig0, 2), _cbuf(eig1, 2)
+        p0, p1 = C.c_double(), C.c_double()
+        _lib.call("qsv_measure_probs", self._h, int(index), _ptr(e0), _ptr(e1), C.byref(p0), C.byref(p1))
+        return p0.value, p1.value
+
+    def collapse(self, index: int, eig, scale: float) -> "DeviceState":
+        """Project qubit ``index`` on ``eig`` (unconjugated) and multiply by ``scale``; register shrinks."""
+        _lib.call("qsv_collapse", self._h, int(index), _ptr(_cbuf(eig, 2)), float(scale))
+        return self
+
+    def insert(self, index: int, amplitudes) -> "DeviceState":
+        a = _cbuf(amplitudes, 2)
+        _lib.call("qsv_insert", self._h, int(index), _ptr(a))
+        return self
+
+    # ---- read-out -----------------------------------------------------------------------------
+    def norm2(self) -> float:
+        v = C.c_double()
+        _lib.call("qsv_norm2", self._h, C.byref(v))
+        return v.value
+
+    def probabilities(self, indices) -> np.ndarray:
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        out = np.empty(idx.size, dtype=np.float64)
+        _lib.call("qsv_probabilities", self._h, idx.ctypes.data_as(C.POINTER(C.c_uint64)), idx.size,
+                  out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def inner(self, other: "DeviceState") -> complex:
+        re, im = C.c_double(), C.c_double()
+        _lib.call("qsv_inner", self._h, other._h, C.byref(re), C.byref(im))
+        return complex(re.value, im.value)
+
+    # ---- timing (HIP events on the register's stream) -----------------------------------------
+    def timer_start(self) -> None:
+        _lib.call("qsv_timer_start", self._h)
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        _lib.call("qsv_timer_stop", self._h, C.byref(ms))
+        return ms.value
+
+
+class QuditState:
+    """``n_modes`` d-level modes, dense complex128, mode 0 slowest (cv_simulator-style mode indices)."""
+
+    def __init__(self, handle: C.c_void_p):
+        self._h = handle
+
+    @classmethod
+    def zeros(cls, n_modes: int, d: int, device: int = 0) -> "QuditState":
+        """All modes in level 0 (vacuum in a Fock basis)."""
+        h = C.c_void_p()
+        _lib.call("qsv_create_qudit", int(n_modes), int(d), int(device), C.byref(h))
+        return cls(h)
+
+    @classmethod
+    def from_numpy(cls, tensor: np.ndarray, device: int = 0) -> "QuditState":
+        tensor = np.asarray(tensor)
+        d = tensor.shape[0]
+        if any(s != d for s in tensor.shape):
+            raise ValueError("all modes must share one local dimension")
+        st = cls.zeros(tensor.ndim, d, device)
+        buf = _cbuf(tensor)
+        _lib.call("qsv_upload", st._h, _ptr(buf), 0, buf.size)
+        return st
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            _lib.load().qsv_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def dims(self) -> tuple[int, int]:
+        n, d = C.c_int(), C.c_int()
+        _lib.call("qsv_qudit_shape", self._h, C.byref(n), C.byref(d))
+        return n.value, d.value
+
+    def to_numpy(self) -> np.ndarray:
+        n, d = self.dims
+        out = np.empty(d ** n, dtype=np.complex128)
+        _lib.call("qsv_download", self._h, _ptr(out), 0, out.size)
+        return out.reshape((d,) * n)
+
+    def sync(self) -> None:
+        _lib.call("qsv_sync", self._h)
+
+    def apply_mode(self, matrix, mode: int) -> "QuditState":
+        _, d = self.dims
+        m = np.asarray(matrix)
+        if m.ndim == 1:
+            _lib.call("qsv_apply_mode1_diag", self._h, int(mode), _ptr(_cbuf(m, d)))
+        else:
+            _lib.call("qsv_apply_mode1", self._h, int(mode), _ptr(_cbuf(m, d * d)))
+        return self
+
+    def apply_two_mode(self, matrix, mode0: int, mode1: int) -> "QuditState":
+        _, d = self.dims
+        m = np.asarray(matrix)
+        if m.ndim == 1 or m.shape == (d, d):   # diagonal given flat or as the (d, d) plane
+            _lib.call("qsv_apply_mode2_diag", self._h, int(mode0), int(mode1), _ptr(_cbuf(m, d * d)))
+        else:
+            _lib.call("qsv_apply_mode2", self._h, int(mode0), int(mode1), _ptr(_cbuf(m, d ** 4)))
+        return self
+
+    def norm2(self) -> float:
+        v = C.c_double()
+        _lib.call("qsv_norm2", self._h, C.byref(v))
+        return v.value
+
+    def timer_start(self) -> None:
+        _lib.call("qsv_timer_start", self._h)
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        _lib.call("qsv_timer_stop", self._h, C.byref(ms))
+        return ms.value
+
+
+def tensor_apply_axis(dev_in: int, dev_out: int, L: int, d_in: int, d_out: int, R: int, matrix, device: int = 0,
+                      stream: int = 0) -> None:
+    """``out[l, :, r] = M @ in[l, :, r]`` on raw device tensors (an MPS site: L = chi_l, R = chi_r)."""
+    m = _cbuf(matrix, d_in * d_out)
+    _lib.call("qsv_tensor_apply_axis", int(device), C.c_void_p(stream), C.c_void_p(dev_in), C.c_void_p(dev_out),
+              int(L), int(d_in), int(d_out), int(R), _ptr(m))

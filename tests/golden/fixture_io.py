@@ -1,0 +1,51 @@
+"""Serialisation of op lists (see ``quantum_computations_amd.workloads``) into ``.npz`` fixtures.
+
+A circuit is stored as a JSON string (names, indices, scalar parameters) plus one stacked complex array with the
+matrices of the ops that carry one, so a fixture is self-contained data: it does not depend on NumPy's random
+streams staying stable, nor on any generator code.
+"""
+from __future__ import annotations
+
+import json
+
+import numpy as np
+
+_SCALARS = ("angle", "theta", "phi", "result", "state", "control")
+
+
+def pack_ops(ops: list[dict]) -> tuple[str, np.ndarray]:
+    meta, mats = [], []
+    for o in ops:
+        entry = {"name": o["name"], "indices": [int(i) for i in o["indices"]]}
+        for key in _SCALARS:
+            if key in o and o[key] is not None:
+                entry[key] = o[key]
+        if o.get("matrix") is not None and o["name"] not in ("Insert", "M"):
+            m = np.asarray(o["matrix"], dtype=np.complex128)
+            entry["mat"] = len(mats)
+            entry["dim"] = int(m.shape[0])
+            padded = np.zeros((4, 4), dtype=np.complex128)
+            if m.shape[0] > 4:
+                raise ValueError("fixtures hold 1- and 2-qubit matrices only")
+            padded[: m.shape[0], : m.shape[1]] = m
+            mats.append(padded)
+        meta.append(entry)
+    stacked = np.stack(mats) if mats else np.zeros((0, 4, 4), dtype=np.complex128)
+    return json.dumps(meta), stacked
+
+
+def unpack_ops(meta_json: str, mats: np.ndarray, state_vectors: dict | None = None) -> list[dict]:
+    """Rebuild ops; ``state_vectors`` maps State names to their 2-vectors (for ``Insert``)."""
+    ops = []
+    for entry in json.loads(str(meta_json)):
+        o = {"name": entry["name"], "indices": list(entry["indices"]), "matrix": None}
+        for key in _SCALARS:
+            if key in entry:
+                o[key] = entry[key]
+        if "mat" in entry:
+            d = entry["dim"]
+            o["matrix"] = np.array(mats[entry["mat"]][:d, :d])
+        if o["name"] == "Insert" and state_vectors is not None:
+            o["vector"] = state_vectors[o["state"]]
+        ops.append(o)
+    return ops

@@ -1,0 +1,346 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE (build container only).
+
+Imports ``/root/reference/simulators`` by path and pushes seeded inputs through its own ``Gate.apply`` /
+``Simulator.run`` / ``cv_simulator`` helpers; what is written are inputs and the reference's outputs -- data,
+no reference code.  The reference does not exist on the GPU box: tests only read the committed ``.npz`` files.
+
+    python tests/golden/generate_golden.py          # rewrites tests/golden/*.npz
+
+Covers SURVEY.md section 8c items (1)-(7).
+"""
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+REFERENCE = Path("/root/reference")
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(REFERENCE))
+
+from fixture_io import pack_ops  # noqa: E402
+from quantum_computations_amd import workloads as W  # noqa: E402
+
+# --- the reference (untrusted public code: imported to be RUN, nothing is copied) ---------------------------
+from simulators.dv_simulator import gates as ref_gates  # noqa: E402
+from simulators.dv_simulator import numpy_quantum as ref_npq  # noqa: E402
+from simulators.dv_simulator.simulator import ClassicalControl as RefControl  # noqa: E402
+from simulators.dv_simulator.simulator import Simulator as RefSimulator  # noqa: E402
+from simulators.dv_simulator.states import State as RefState  # noqa: E402
+from simulators.cv_simulator import gates as ref_cv  # noqa: E402
+from simulators.cv_simulator import utils as ref_cvu  # noqa: E402
+from simulators.cv_simulator.mps import MPS as RefMPS  # noqa: E402
+
+NAMED = ("I", "X", "Y", "Z", "H", "P", "Pdg", "T", "Tdg", "CX", "CZ", "SWAP")
+
+
+def ref_gate(o: dict):
+    name, idx = o["name"], o["indices"]
+    if name in NAMED:
+        g = getattr(ref_gates, name)(*idx)
+    elif name == "RZ":
+        g = ref_gates.RZ(idx[0], o["angle"])
+    elif name == "M":
+        g = ref_gates.M(idx[0], o["theta"], o["phi"], result=o.get("result"))
+    elif name == "Insert":
+        g = ref_gates.Insert(idx[0], RefState[o["state"]])
+    else:
+        g = ref_gates.Gate(list(idx), np.asarray(o["matrix"]))
+    ctl = o.get("control")
+    if ctl is not None:
+        g = RefControl(g, list(ctl.get("pos", [])), list(ctl.get("neg", [])))
+    return g
+
+
+def ref_run(ops, state):
+    sim = RefSimulator([ref_gate(o) for o in ops])
+    out = sim.run(state)
+    return out, sim.results
+
+
+def complex_ket(n, rng):
+    v = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    return v / np.linalg.norm(v)
+
+
+def save(name, **arrays):
+    path = HERE / name
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path.name}: {path.stat().st_size / 1024:.1f} KiB")
+
+
+# (1) every gate class on every position, n in {1, 2, 3, 5} --------------------------------------------------
+def gen_single_gates():
+    rng = np.random.default_rng(1)
+    out = {}
+    cases = []
+    for n in (1, 2, 3, 5):
+        ket = complex_ket(n, rng)
+        out[f"in_n{n}"] = ket
+        results = []
+        for name in ("I", "X", "Y", "Z", "H", "P", "Pdg", "T", "Tdg"):
+            for q in range(n):
+                o = W.op(name, q)
+                results.append(ref_gate(o).apply(ket))
+                cases.append({"n": n, "name": name, "indices": [q], "row": len(results) - 1})
+        for q in range(n):
+            angle = float(rng.uniform(-np.pi, np.pi))
+            results.append(ref_gates.RZ(q, angle).apply(ket))
+            cases.append({"n": n, "name": "RZ", "indices": [q], "angle": angle, "row": len(results) - 1})
+        for name in ("CX", "CZ", "SWAP"):
+            for q0 in range(n):
+                for q1 in range(n):
+                    if q0 != q1:
+                        results.append(getattr(ref_gates, name)(q0, q1).apply(ket))
+                        cases.append({"n": n, "name": name, "indices": [q0, q1], "row": len(results) - 1})
+        out[f"out_n{n}"] = np.stack([np.asarray(r, dtype=np.complex128) for r in results])
+    # real-ket dtype behaviour (H on a real ket stays float64, T makes it complex128)
+    real_ket = np.array([0.6, 0.0, 0.8, 0.0])
+    out["real_in"] = real_ket
+    out["real_H1"] = ref_gates.H(1).apply(real_ket)
+    out["real_T0"] = ref_gates.T(0).apply(real_ket)
+    out["int_X0"] = ref_gates.X(0).apply(np.array([1, 0, 0, 0]))
+    save("dv_single_gates.npz", cases=json.dumps(cases), **out)
+
+
+# (2) expand_gate / permute_tensor_product tables -------------------------------------------------------------
+def gen_expand_gate():
+    rng = np.random.default_rng(2)
+    u2, u4 = W.haar_unitary(2, rng), W.haar_unitary(4, rng)
+    arrays, cases = {"u2": u2, "u4": u4}, []
+    for label, m, N, targets in [("cx_n3_t20", ref_npq.CX, 3, [2, 0]), ("cx_n3_t01", ref_npq.CX, 3, [0, 1]),
+                                 ("u2_n3_t1", u2, 3, [1]), ("u4_n4_t31", u4, 4, [3, 1]),
+                                 ("u4_n4_t02", u4, 4, [0, 2]), ("swap_n4_t03", ref_npq.SWAP, 4, [0, 3])]:
+        arrays[label] = ref_npq.expand_gate(np.asarray(m), N, list(targets))
+        cases.append({"label": label, "N": N, "targets": targets,
+                      "matrix": "u2" if m is u2 else "u4" if m is u4 else label.split("_")[0].upper()})
+    ket = complex_ket(4, rng)
+    arrays["perm_in"] = ket
+    for label, order in [("perm_1302", [1, 3, 0, 2]), ("perm_3210", [3, 2, 1, 0]), ("perm_0123", [0, 1, 2, 3])]:
+        arrays[label] = ref_npq.permute_tensor_product(ket, order)
+        cases.append({"label": label, "order": order})
+    op = ref_npq.expand_gate(u4, 3, [0, 2])
+    arrays["perm_op_in"] = op
+    arrays["perm_op_201"] = ref_npq.permute_tensor_product(op, [2, 0, 1])
+    save("dv_expand_gate.npz", cases=json.dumps(cases), **arrays)
+
+
+# (3) cfg1: 4-qubit random Clifford circuits -------------------------------------------------------------------
+def gen_clifford():
+    arrays, seeds = {}, list(range(6))
+    for seed in seeds:
+        ops = W.random_clifford_circuit(4, 20, seed)
+        final, _ = ref_run(ops, [RefState.ZERO] * 4)
+        meta, mats = pack_ops(ops)
+        arrays[f"meta_{seed}"], arrays[f"mats_{seed}"] = meta, mats
+        arrays[f"final_{seed}"] = np.asarray(final)
+    save("dv_clifford_n4.npz", seeds=np.array(seeds), **arrays)
+
+
+# (4) depth-100 random circuits at n in {6, 8, 10} (the cfg2 generator at sizes the reference can run) ---------
+def gen_random_circuits():
+    arrays, cases = {}, []
+    for n, depth, seed in [(6, 100, 106), (8, 100, 108), (10, 100, 110), (7, 60, 7), (9, 40, 9)]:
+        ops = W.random_circuit(n, depth, seed)
+        init = W.random_ket(n, seed)
+        final, _ = ref_run(ops, init)
+        tag = f"n{n}_s{seed}"
+        arrays[f"meta_{tag}"], arrays[f"mats_{tag}"] = pack_ops(ops)
+        arrays[f"init_{tag}"], arrays[f"final_{tag}"] = init, np.asarray(final, dtype=np.complex128)
+        cases.append({"tag": tag, "n": n, "depth": depth, "seed": seed})
+        print(f"  random circuit n={n} depth={depth} done")
+    save("dv_random_circuits.npz", cases=json.dumps(cases), **arrays)
+
+
+# (5) measurement, insertion, classical control, density matrices -----------------------------------------------
+def gen_measure_insert():
+    rng = np.random.default_rng(5)
+    arrays, cases = {}, []
+    for n in (1, 3, 4):
+        ket = complex_ket(n, rng)
+        arrays[f"ket_n{n}"] = ket
+        for label, theta, phi in [("MZ", 0.0, 0.0), ("MX", np.pi / 2, 0.0), ("Mgen", 0.7, 1.3), ("Mgen2", 2.1, -0.4)]:
+            for q in range(n):
+                for result in (0, 1):
+                    gate = ref_gates.M(q, theta, phi, result=result)
+                    out, s = gate.apply(ket)
+                    # branch norms exactly as gates.py:173-181 computes them, with the reference's primitives
+                    rot = ref_npq.axis_rotation(phi, [0, 0, 1]) @ ref_npq.axis_rotation(theta, [0, 1, 0])
+                    ops = [ref_npq.IDTY] * n
+                    ops[q] = (rot @ ref_npq.ZERO, rot @ ref_npq.ONE)[result]
+                    norm = ref_npq.norm(ref_npq.tensor(*ops) @ ket)
+                    key = f"{label}_n{n}_q{q}_r{result}"
+                    arrays[key] = np.asarray(out, dtype=np.complex128)
+                    cases.append({"kind": "measure", "key": key, "n": n, "q": q, "theta": theta, "phi": phi,
+                                  "result": result, "norm": float(norm), "s": int(s)})
+    # insert chains from the empty register
+    chains = {
+        "ins_a": [(0, "ZERO"), (1, "PLUS"), (1, "ONE")],
+        "ins_b": [(0, "T"), (0, "H"), (1, "MINUS"), (3, "TDG"), (2, "ONE")],
+        "ins_c": [(0, "PLUS"), (0, "PLUS"), (2, "T")],
+    }
+    for key, chain in chains.items():
+        ops = [{"name": "Insert", "indices": [q], "matrix": None, "state": s} for q, s in chain]
+        out, _ = ref_run(ops, None)
+        arrays[key] = np.asarray(out, dtype=np.complex128)
+        cases.append({"kind": "insert_chain", "key": key, "chain": chain})
+    # insertion into a random register at every position
+    ket3 = arrays["ket_n3"]
+    for q in range(4):
+        key = f"ins_n3_q{q}"
+        arrays[key] = np.asarray(ref_gates.Insert(q, RefState.T).apply(ket3), dtype=np.complex128)
+        cases.append({"kind": "insert", "key": key, "n": 3, "q": q, "state": "T"})
+    # classical control: teleportation-style circuit with forced outcomes
+    for r0 in (0, 1):
+        for r1 in (0, 1):
+            ops = [
+                {"name": "Insert", "indices": [0], "matrix": None, "state": "T"},
+                {"name": "Insert", "indices": [1], "matrix": None, "state": "ZERO"},
+                {"name": "Insert", "indices": [2], "matrix": None, "state": "ZERO"},
+                W.op("H", 1), W.op("CX", 1, 2), W.op("CX", 0, 1), W.op("H", 0),
+                {"name": "M", "indices": [0], "matrix": None, "theta": 0.0, "phi": 0.0, "result": r0},
+                {"name": "M", "indices": [0], "matrix": None, "theta": 0.0, "phi": 0.0, "result": r1},
+                {**W.op("X", 0), "control": {"pos": [1], "neg": []}},
+                {**W.op("Z", 0), "control": {"pos": [0], "neg": []}},
+                {**W.op("H", 0), "control": {"pos": [], "neg": [0, 1]}},
+            ]
+            out, results = ref_run(ops, None)
+            key = f"ctl_{r0}{r1}"
+            arrays[key] = np.asarray(out, dtype=np.complex128)
+            arrays[f"{key}_meta"], arrays[f"{key}_mats"] = pack_ops(ops)
+            cases.append({"kind": "control", "key": key, "results": [int(r) for r in results]})
+    # density matrices, n <= 3
+    for n in (1, 2, 3):
+        ket = complex_ket(n, rng)
+        rho = np.outer(ket, ket.conj())
+        mix = 0.7 * rho + 0.3 * np.identity(1 << n) / (1 << n)
+        arrays[f"rho_n{n}"] = mix
+        gates = [W.op("H", 0), W.op("T", n - 1), W.op("U", 0, matrix=W.haar_unitary(2, rng))]
+        if n >= 2:
+            gates += [W.op("CX", n - 1, 0), W.op("U", 0, n - 1, matrix=W.haar_unitary(4, rng))]
+        for j, o in enumerate(gates):
+            key = f"rho_n{n}_g{j}"
+            arrays[key] = np.asarray(ref_gate(o).apply(mix), dtype=np.complex128)
+            arrays[f"{key}_meta"], arrays[f"{key}_mats"] = pack_ops([o])
+            cases.append({"kind": "density", "key": key, "n": n})
+    save("dv_measure_insert.npz", cases=json.dumps(cases), **arrays)
+
+
+# (6) the 3-qubit Grover anchor and the hand-decomposed CCZ ---------------------------------------------------
+def gen_grover():
+    arrays, cases = {}, []
+    for tagged in ([3, 6], [0, 4], [2, 7]):
+        ops = W.grover3_ops(tagged)
+        out, _ = ref_run(ops, None)
+        key = "grover_" + "".join(map(str, tagged))
+        arrays[key] = np.asarray(out, dtype=np.complex128)
+        cases.append({"key": key, "tagged": tagged})
+    ccz = np.zeros((8, 8), dtype=np.complex128)
+    for col in range(8):
+        out, _ = ref_run(W.ccz_ops(), ref_npq.basis_state(col, 3))
+        ccz[:, col] = out
+    arrays["ccz_operator"] = ccz
+    save("dv_grover3.npz", cases=json.dumps(cases), **arrays)
+
+
+# (7) cv_simulator: the d x d / (d, d)-plane linear maps behind the gates, and short dense sequences -----------
+def gen_cv():
+    arrays, cases = {}, []
+    d = 32
+    qs = np.linspace(-8.0, 8.0, d)
+    arrays["qs32"] = qs
+    eye = np.identity(d, dtype=np.complex128)
+
+    def single_mode_matrix(gate):
+        # column j of the operator = the gate applied to the j-th grid basis vector on a 1-mode MPS
+        cols = []
+        for j in range(d):
+            mps = RefMPS(qs, [eye[:, j].copy()])
+            gate.apply(mps, rng=None)
+            cols.append(mps[0].reshape(-1))
+        return np.stack(cols, axis=1)
+
+    for label, gate in [("X_0.7", ref_cv.X(0, 0.7)), ("X_1.3_dag", ref_cv.X(0, 1.3, dagger=True)),
+                        ("F", ref_cv.F(0)), ("F_dag", ref_cv.F(0, dagger=True)),
+                        ("Z_0.9", ref_cv.Z(0, 0.9)), ("P_0.5", ref_cv.P(0, 0.5)),
+                        ("P_0.5_dag", ref_cv.P(0, 0.5, dagger=True))]:
+        arrays["cv1_" + label] = single_mode_matrix(gate)
+        cases.append({"kind": "single", "key": "cv1_" + label})
+    for theta in (0.4, -1.1, np.pi / 2):
+        key = f"cv1_rotation_{theta:.3f}"
+        arrays[key] = ref_cvu.rotation(qs, eye, theta, axis=0)
+        cases.append({"kind": "rotation", "key": key, "theta": float(theta)})
+
+    # two-mode gates on small grids: the full d^2 x d^2 operator, truncation disabled
+    d2 = 8
+    qs2 = np.linspace(-4.0, 4.0, d2)
+    arrays["qs8"] = qs2
+    eye2 = np.identity(d2, dtype=np.complex128)
+    exact = {"rel_err": 0.0, "abs_err": 0.0}
+
+    def two_mode_operator(make_gate):
+        op = np.zeros((d2 * d2, d2 * d2), dtype=np.complex128)
+        for j0 in range(d2):
+            for j1 in range(d2):
+                mps = RefMPS(qs2, [eye2[:, j0].copy(), eye2[:, j1].copy()])
+                make_gate().apply(mps, rng=None)
+                op[:, j0 * d2 + j1] = mps.contract().reshape(-1)
+        return op
+
+    two_mode = {
+        "cv2_CZ_0.8": lambda: ref_cv.CZ(0, 1, 0.8, **exact),
+        "cv2_CZ_0.8_dag": lambda: ref_cv.CZ(0, 1, 0.8, dagger=True, **exact),
+        "cv2_BS_pi4": lambda: ref_cv.BS(0, 1, np.pi / 4, **exact),
+        "cv2_BS_0.3_rev": lambda: ref_cv.BS(1, 0, 0.3, **exact),
+        "cv2_BS_0.3_dag": lambda: ref_cv.BS(0, 1, 0.3, dagger=True, **exact),
+        "cv2_CX_1.0": lambda: ref_cv.CX(0, 1, 1.0, **exact),
+        "cv2_CX_1.0_rev": lambda: ref_cv.CX(1, 0, 1.0, **exact),
+        "cv2_SWAP": lambda: ref_cv.SWAP(0, 1, **exact),
+    }
+    for key, make in two_mode.items():
+        arrays[key] = two_mode_operator(make)
+        cases.append({"kind": "two_mode", "key": key})
+
+    # a short 3-mode sequence on random product-free input, dense result via MPS.contract()
+    rng = np.random.default_rng(7)
+    d3 = 12
+    qs3 = np.linspace(-5.0, 5.0, d3)
+    arrays["qs12"] = qs3
+    psi = rng.standard_normal((d3, d3, d3)) + 1j * rng.standard_normal((d3, d3, d3))
+    psi /= np.linalg.norm(psi)
+    arrays["cv_seq_in"] = psi
+    # exact MPS of psi by two SVD splits (rank is at most d3 and d3, nothing truncated)
+    u, s, vh = np.linalg.svd(psi.reshape(d3, d3 * d3), full_matrices=False)
+    a0 = (u * s).reshape(1, d3, -1)
+    rest = vh.reshape(-1, d3, d3)
+    u2, s2, vh2 = np.linalg.svd(rest.reshape(-1, d3), full_matrices=False)
+    a1 = (u2 * s2).reshape(rest.shape[0], d3, -1)
+    a2 = vh2.reshape(-1, d3, 1)
+    mps = RefMPS(qs3, [a0, a1, a2])
+    assert np.allclose(mps.contract(), psi)
+    seq = [ref_cv.F(0), ref_cv.CZ(0, 1, 0.6, **exact), ref_cv.X(1, 0.5), ref_cv.P(2, 0.3),
+           ref_cv.CZ(2, 1, 0.4, dagger=True, **exact), ref_cv.Z(0, 1.1), ref_cv.F(2, dagger=True)]
+    for g in seq:
+        g.apply(mps, rng=None)
+    arrays["cv_seq_out"] = mps.contract()
+    cases.append({"kind": "sequence", "key": "cv_seq_out",
+                  "gates": ["F(0)", "CZ(0,1,0.6)", "X(1,0.5)", "P(2,0.3)", "CZ(2,1,0.4)^dag", "Z(0,1.1)", "F(2)^dag"]})
+    save("cv_operators.npz", cases=json.dumps(cases), **arrays)
+
+
+if __name__ == "__main__":
+    import logging
+    logging.getLogger("simulators").setLevel(logging.ERROR)
+    gen_single_gates()
+    gen_expand_gate()
+    gen_clifford()
+    gen_random_circuits()
+    gen_measure_insert()
+    gen_grover()
+    gen_cv()
