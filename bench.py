@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: gate-apps/sec + achieved HBM GB/s on a 28-qubit complex128 register per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One *step* = one pass of BASELINE.json's config 2 circuit (depth-100 random 1+2-qubit gates, generator of
+SURVEY.md 8d, seed 100) over the register, every gate going through the public ``Gate.apply`` -> C ABI -> HIP
+path with the register resident in HBM.  N = 1: n = 28 qubits (4 GiB).  N > 1: weak scaling, n = 28 + log2(N)
+qubits sharded over the ranks (top qubits = rank id), gates on remote qubits exchange half shards over RCCL;
+``value`` is reported in 28-qubit gate-app equivalents (amplitude updates / 2^28 per second) so that it is the
+whole-job aggregate, and the raw gate-apps/s on the larger register is given beside it.
+
+Rank 0 prints ONE JSON line.  ``roofline`` is measured live with HIP events around every dense-kernel launch of
+the timed region; ``cpu_baseline`` is the C/OpenMP restatement (oracle/, "port") timed on this host on a bounded
+prefix of the same circuit (rank 0, N = 1 only), and doubles as a full-size parity check.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+QUBITS_PER_GPU = 28
+DEPTH = 100
+CIRCUIT_SEED = 100
+STATE_SEED = 28
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
+
+
+def classify(op) -> str:
+    """Which kernel family a gate lands in with specialisation on (mirrors qsv_api.hip's selection)."""
+    m = np.asarray(op["matrix"])
+    if op["name"] in ("CX", "CZ", "SWAP"):
+        return op["name"].lower()
+    if np.count_nonzero(m - np.diag(np.diagonal(m))) == 0:
+        return "diag"
+    return "dense1" if len(op["indices"]) == 1 else "dense2"
+
+
+def cpu_baseline(ops, dev, n, budget_s=12.0):
+    """Time the C/OpenMP oracle on a prefix of the circuit, then use the result as a full-size parity check."""
+    from oracle import c_oracle   # checker / baseline only -- never on the product path
+
+    c_oracle.load()
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
+    host = dev.to_numpy()                       # the same initial state the GPU starts from
+    t_total, done = 0.0, 0
+    for op in ops:
+        t0 = time.perf_counter()
+        c_oracle.apply_gate_inplace(host, op["matrix"], op["indices"])
+        t_total += time.perf_counter() - t0
+        done += 1
+        if t_total > budget_s and done >= 4:
+            break
+    # parity at full size: run the same prefix on the GPU and compare every amplitude
+    from quantum_computations_amd import workloads as W
+    for gate in W.to_gates(ops[:done]):
+        gate.apply(dev)
+    err = float(np.max(np.abs(dev.to_numpy() - host)))
+    return {
+        "value": done / t_total, "unit": "gate-apps/s", "cores": threads, "kind": "port",
+        "sample": f"first {done} of the {len(ops)} gates of the same n={n} circuit, C/OpenMP restatement "
+                  f"(oracle/csrc/qsv_oracle.c), {t_total:.1f} s",
+    }, err
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--qubits-per-gpu", type=int, default=QUBITS_PER_GPU)
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the gate path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    from quantum_computations_amd import workloads as W
+
+    g_bits = (world - 1).bit_length()
+    if 1 << g_bits != world:
+        raise SystemExit("the register shards over a power-of-two number of GPUs")
+    n_local = args.qubits_per_gpu
+    n = n_local + g_bits
+    ops = W.random_circuit(n, DEPTH, CIRCUIT_SEED)
+    gates = W.to_gates(ops)
+    classes = [classify(o) for o in ops]
+
+    if world == 1:
+        from quantum_computations_amd.device import DeviceState
+        dev = DeviceState.random(n, seed=STATE_SEED, device=local_rank)
+        barrier = lambda: None
+        reduce_max = lambda x: x
+        comm_info = {}
+    else:
+        import torch.distributed as dist
+        from quantum_computations_amd.distributed import ShardedState
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dev = ShardedState.random(n, seed=STATE_SEED, device=local_rank)
+        barrier = dist.barrier
+
+        def reduce_max(x):
+            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        comm_info = {}
+
+    cpu, parity_err = (None, None)
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu, parity_err = cpu_baseline(ops, dev, n)
+        dev.fill_random(STATE_SEED)             # restart from the initial state
+
+    def step(record: bool, slot0: int = 0):
+        slot = slot0
+        for gate in gates:
+            if record:
+                dev.event_record(slot)
+            gate.apply(dev)
+            if record:
+                dev.event_record(slot + 1)
+            slot += 2
+        return slot
+
+    for _ in range(args.warmup):
+        step(False)
+    record = world == 1 and args.steps * DEPTH * 2 <= 16000
+    barrier()
+    torch.cuda.synchronize()
+    dev.sync()
+    t0 = time.perf_counter()
+    slot = 0
+    for _ in range(args.steps):
+        slot = step(record, slot)
+    dev.sync()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = reduce_max(time.perf_counter() - t0)
+
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+
+    gate_apps = args.steps * DEPTH
+    register_rate = gate_apps / elapsed                       # gate-apps/s on the n-qubit register
+    value = register_rate * (1 << g_bits)                      # 28-qubit equivalents, whole job
+    bytes_per_gate_per_gpu = 2 * 16 * (1 << n_local)
+    result = {
+        "metric": "gate_apps_per_sec", "value": value, "unit": "gate-apps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"{n}-qubit complex128 state vector ({n_local} qubits = {16 * (1 << n_local) / 2**30:.0f} GiB "
+                        f"per GPU), depth-{DEPTH} random 1+2-qubit gates (BASELINE.json configs[1], seed {CIRCUIT_SEED})",
+            "n_qubits": n, "depth": DEPTH, "gate_mix": {c: classes.count(c) for c in sorted(set(classes))},
+            "sharding": f"top {g_bits} qubits = rank id" if g_bits else "single GPU",
+            "unit_note": "value = gate-apps/s on the full register x 2^(n-28): 28-qubit gate-app equivalents",
+        },
+        "gate_apps_per_sec_on_register": register_rate,
+        "algorithmic_GBps_per_gpu": bytes_per_gate_per_gpu * register_rate / 1e9,
+    }
+    if record:
+        per_class = {}
+        for s in range(args.steps):
+            for i, c in enumerate(classes):
+                a = 2 * (s * DEPTH + i)
+                per_class.setdefault(c, []).append(dev.event_elapsed_ms(a, a + 1))
+        dense = per_class.get("dense1", []) + per_class.get("dense2", [])
+        avg_ms = float(np.mean(dense))
+        achieved = bytes_per_gate_per_gpu / (avg_ms * 1e-3) / 1e9
+        result["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "kernel": "k_dense (dense 1- and 2-qubit gates, all target-bit regimes)",
+            "algorithmic_bytes_per_launch": bytes_per_gate_per_gpu, "avg_launch_ms": avg_ms,
+            "launches_timed": len(dense),
+        }
+        result["per_kernel_class_ms"] = {c: {"launches": len(v), "avg_ms": float(np.mean(v)),
+                                             "equiv_GBps": bytes_per_gate_per_gpu / (np.mean(v) * 1e-3) / 1e9}
+                                         for c, v in sorted(per_class.items())}
+    if cpu is not None:
+        result["cpu_baseline"] = cpu
+        result["parity_max_abs_err_vs_cpu_at_full_size"] = parity_err
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

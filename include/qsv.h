@@ -145,6 +145,10 @@ int qsv_tensor_apply_axis(int device, void *hip_stream, const void *dev_in, void
 /* ---- timing on the state's stream (HIP events), for bench.py's roofline figures ----------- */
 int qsv_timer_start(qsv_state *st);
 int qsv_timer_stop(qsv_state *st, float *elapsed_ms); /* records, synchronises the event, returns ms */
+/* Non-blocking marks: record HIP event number `slot` (0 <= slot < 16384) on the state's stream;
+ * qsv_event_elapsed_ms waits for mark `slot_b` and returns the device time between two marks. */
+int qsv_event_record(qsv_state *st, int slot);
+int qsv_event_elapsed_ms(qsv_state *st, int slot_a, int slot_b, float *elapsed_ms);
 
 #ifdef __cplusplus
 }

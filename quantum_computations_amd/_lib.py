@@ -63,6 +63,8 @@ SIGNATURES: dict[str, list] = {
                               C.c_uint64, C.c_void_p],
     "qsv_timer_start": [_state_p],
     "qsv_timer_stop": [_state_p, C.POINTER(C.c_float)],
+    "qsv_event_record": [_state_p, C.c_int],
+    "qsv_event_elapsed_ms": [_state_p, C.c_int, C.c_int, C.POINTER(C.c_float)],
 }
 
 _lib = None

@@ -179,6 +179,8 @@ int qsv_destroy(qsv_state *st) {
     if (st->dev_matrix) (void)hipFree(st->dev_matrix);
     if (st->ev_start) (void)hipEventDestroy(st->ev_start);
     if (st->ev_stop) (void)hipEventDestroy(st->ev_stop);
+    for (hipEvent_t ev : st->marks)
+        if (ev) (void)hipEventDestroy(ev);
     delete st;
     return QSV_OK;
 }
@@ -624,6 +626,28 @@ int qsv_timer_stop(qsv_state *st, float *elapsed_ms) {
     QSV_HIP(hipEventRecord(st->ev_stop, st->stream));
     QSV_HIP(hipEventSynchronize(st->ev_stop));
     QSV_HIP(hipEventElapsedTime(elapsed_ms, st->ev_start, st->ev_stop));
+    return QSV_OK;
+}
+
+int qsv_event_record(qsv_state *st, int slot) {
+    if (!valid(st)) return qsv_fail(QSV_EINVAL, "null state");
+    if (slot < 0 || slot >= 16384) return qsv_fail(QSV_EINVAL, "event slot out of range");
+    QSV_HIP(hipSetDevice(st->device));
+    if (st->marks.size() <= static_cast<size_t>(slot)) st->marks.resize(slot + 1, nullptr);
+    if (!st->marks[slot]) QSV_HIP(hipEventCreate(&st->marks[slot]));
+    QSV_HIP(hipEventRecord(st->marks[slot], st->stream));
+    return QSV_OK;
+}
+
+int qsv_event_elapsed_ms(qsv_state *st, int slot_a, int slot_b, float *elapsed_ms) {
+    if (!valid(st) || !elapsed_ms) return qsv_fail(QSV_EINVAL, "null pointer");
+    const int hi = slot_a > slot_b ? slot_a : slot_b;
+    if (slot_a < 0 || slot_b < 0 || static_cast<size_t>(hi) >= st->marks.size() || !st->marks[slot_a] ||
+        !st->marks[slot_b])
+        return qsv_fail(QSV_EINVAL, "event slot was never recorded");
+    QSV_HIP(hipSetDevice(st->device));
+    QSV_HIP(hipEventSynchronize(st->marks[slot_b]));
+    QSV_HIP(hipEventElapsedTime(elapsed_ms, st->marks[slot_a], st->marks[slot_b]));
     return QSV_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "qsv.h"
 
@@ -63,6 +64,7 @@ struct qsv_state {
     double *dev_matrix = nullptr;     // device: matrix / table of the generic kernels
     size_t dev_matrix_bytes = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::vector<hipEvent_t> marks;    // lazily created events of qsv_event_record
     // options
     int specialize = 1;
     int unroll = 0;

@@ -252,6 +252,16 @@ class DeviceState:
         return ms.value
 
 
+    def event_record(self, slot: int) -> None:
+        """Non-blocking HIP event mark number ``slot`` on the register's stream."""
+        _lib.call("qsv_event_record", self._h, int(slot))
+
+    def event_elapsed_ms(self, slot_a: int, slot_b: int) -> float:
+        ms = C.c_float()
+        _lib.call("qsv_event_elapsed_ms", self._h, int(slot_a), int(slot_b), C.byref(ms))
+        return ms.value
+
+
 class QuditState:
     """``n_modes`` d-level modes, dense complex128, mode 0 slowest (cv_simulator-style mode indices)."""
 

@@ -163,3 +163,43 @@ def test_oracle_is_linear_and_unitary(n):
     assert np.max(np.abs(fab - (0.3 * fa + (0.1 - 0.7j) * fb))) < 1e-13
     assert abs(np.linalg.norm(fa) - 1) < 1e-13
     assert abs(np.vdot(fa, fb) - np.vdot(a, b)) < 1e-13
+
+
+# ---- the C restatement (oracle/csrc/qsv_oracle.c) is pinned to the same vectors ------------------------------
+def test_c_oracle_random_circuits(golden):
+    from oracle import c_oracle
+    g = golden["dv_random_circuits"]
+    for case in golden.cases("dv_random_circuits"):
+        tag = case["tag"]
+        ops = unpack_ops(g[f"meta_{tag}"], g[f"mats_{tag}"])
+        state = np.array(g[f"init_{tag}"], dtype=np.complex128)
+        c_oracle.run_circuit_inplace(ops, state)
+        assert np.max(np.abs(state - g[f"final_{tag}"])) < 1e-12, tag
+
+
+def test_c_oracle_every_position_vs_numpy_oracle():
+    from oracle import c_oracle
+    rng = np.random.default_rng(0)
+    n = 7
+    ket = W.random_ket(n, 70)
+    state = ket.copy()
+    want = ket
+    for q0 in range(n):
+        u = W.haar_unitary(2, rng)
+        c_oracle.apply_gate_inplace(state, u, [q0])
+        want = O.apply_gate(want, u, [q0])
+        for q1 in range(n):
+            if q1 != q0:
+                u = W.haar_unitary(4, rng)
+                c_oracle.apply_gate_inplace(state, u, [q0, q1])
+                want = O.apply_gate(want, u, [q0, q1])
+    assert np.max(np.abs(state - want)) < 1e-12
+
+
+def test_c_oracle_dense_matvec_is_the_literal_algorithm(golden):
+    from oracle import c_oracle
+    g = golden["dv_expand_gate"]
+    full = g["u4_n4_t31"]
+    ket = g["perm_in"]
+    assert np.max(np.abs(c_oracle.dense_matvec(full, ket) - full @ ket)) < TOL
+    assert np.max(np.abs(c_oracle.dense_matvec(full, ket) - O.apply_gate(ket, g["u4"], [3, 1]))) < TOL
