@@ -36,22 +36,16 @@ STATE_SEED = 28
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
 
 
-def classify(op) -> str:
-    """Which kernel family a gate lands in with specialisation on (mirrors qsv_api.hip's selection)."""
-    m = np.asarray(op["matrix"])
-    if op["name"] in ("CX", "CZ", "SWAP"):
-        return op["name"].lower()
-    if np.count_nonzero(m - np.diag(np.diagonal(m))) == 0:
-        return "diag"
-    return "dense1" if len(op["indices"]) == 1 else "dense2"
+CPU_THREADS = 16        # the GPU box's CPU share for one GPU
 
 
 def cpu_baseline(ops, dev, n, budget_s=12.0):
     """Time the C/OpenMP oracle on a prefix of the circuit, then use the result as a full-size parity check."""
     from oracle import c_oracle   # checker / baseline only -- never on the product path
 
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(CPU_THREADS, len(os.sched_getaffinity(0)))))
     c_oracle.load()
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
+    threads = int(os.environ["OMP_NUM_THREADS"])
     host = dev.to_numpy()                       # the same initial state the GPU starts from
     t_total, done = 0.0, 0
     for op in ops:
@@ -104,7 +98,7 @@ def main():
     n = n_local + g_bits
     ops = W.random_circuit(n, DEPTH, CIRCUIT_SEED)
     gates = W.to_gates(ops)
-    classes = [classify(o) for o in ops]
+    gate_names = [o["name"] for o in ops]
 
     if world == 1:
         from quantum_computations_amd.device import DeviceState
@@ -142,6 +136,12 @@ def main():
             slot += 2
         return slot
 
+    # which kernel each gate of the circuit lands in (asked of the library, not guessed)
+    kernels = []
+    if world == 1:
+        for gate in gates:
+            gate.apply(dev)
+            kernels.append(dev.last_kernel())
     for _ in range(args.warmup):
         step(False)
     record = world == 1 and args.steps * DEPTH * 2 <= 16000
@@ -174,7 +174,8 @@ def main():
         "config": {
             "workload": f"{n}-qubit complex128 state vector ({n_local} qubits = {16 * (1 << n_local) / 2**30:.0f} GiB "
                         f"per GPU), depth-{DEPTH} random 1+2-qubit gates (BASELINE.json configs[1], seed {CIRCUIT_SEED})",
-            "n_qubits": n, "depth": DEPTH, "gate_mix": {c: classes.count(c) for c in sorted(set(classes))},
+            "n_qubits": n, "depth": DEPTH,
+            "gate_mix": {c: gate_names.count(c) for c in sorted(set(gate_names))},
             "sharding": f"top {g_bits} qubits = rank id" if g_bits else "single GPU",
             "unit_note": "value = gate-apps/s on the full register x 2^(n-28): 28-qubit gate-app equivalents",
         },
@@ -182,24 +183,36 @@ def main():
         "algorithmic_GBps_per_gpu": bytes_per_gate_per_gpu * register_rate / 1e9,
     }
     if record:
-        per_class = {}
+        per_kernel = {}
         for s in range(args.steps):
-            for i, c in enumerate(classes):
+            for i, c in enumerate(kernels):
                 a = 2 * (s * DEPTH + i)
-                per_class.setdefault(c, []).append(dev.event_elapsed_ms(a, a + 1))
-        dense = per_class.get("dense1", []) + per_class.get("dense2", [])
-        avg_ms = float(np.mean(dense))
+                per_kernel.setdefault(c, []).append(dev.event_elapsed_ms(a, a + 1))
+        # dominant kernel = the full-traffic dense instantiation with the most device time
+        full = {k: v for k, v in per_kernel.items() if k.startswith("k_dense<")}
+        dominant = max(full, key=lambda k: sum(full[k]))
+        avg_ms = float(np.mean(full[dominant]))
         achieved = bytes_per_gate_per_gpu / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        pmc = REPO / "profiles" / "pmc_traffic.json"        # written by tools/summarize_profile.py from rocprofv3 --pmc
+        if pmc.exists():
+            entry = json.loads(pmc.read_text()).get(dominant)
+            if entry:
+                traffic, traffic_src = entry["hbm_bytes_per_launch"], entry["source"]
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-            "kernel": "k_dense (dense 1- and 2-qubit gates, all target-bit regimes)",
-            "algorithmic_bytes_per_launch": bytes_per_gate_per_gpu, "avg_launch_ms": avg_ms,
-            "launches_timed": len(dense),
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": dominant, "algorithmic_bytes_per_launch": bytes_per_gate_per_gpu,
+            "avg_launch_ms": avg_ms, "launches_timed": len(full[dominant]),
         }
-        result["per_kernel_class_ms"] = {c: {"launches": len(v), "avg_ms": float(np.mean(v)),
-                                             "equiv_GBps": bytes_per_gate_per_gpu / (np.mean(v) * 1e-3) / 1e9}
-                                         for c, v in sorted(per_class.items())}
+        all_full = [t for v in full.values() for t in v]
+        result["dense_full_traffic_all_kernels"] = {
+            "launches": len(all_full), "avg_ms": float(np.mean(all_full)),
+            "GBps": bytes_per_gate_per_gpu / (np.mean(all_full) * 1e-3) / 1e9,
+            "frac_of_peak": bytes_per_gate_per_gpu / (np.mean(all_full) * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        result["per_kernel_ms"] = {c: {"launches": len(v), "avg_ms": float(np.mean(v)),
+                                       "equiv_GBps": bytes_per_gate_per_gpu / (np.mean(v) * 1e-3) / 1e9}
+                                   for c, v in sorted(per_kernel.items())}
     if cpu is not None:
         result["cpu_baseline"] = cpu
         result["parity_max_abs_err_vs_cpu_at_full_size"] = parity_err

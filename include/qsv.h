@@ -49,7 +49,7 @@ enum {
                                reduced-traffic kernels; 0: every gate runs the dense kernel */
     QSV_OPT_UNROLL = 2,     /* work items in flight per thread (1,2,4,8); 0 = built-in default */
     QSV_OPT_GRID_CAP = 3,   /* max workgroups per launch; 0 = one tile per workgroup */
-    QSV_OPT_NONTEMPORAL = 4 /* 1: nontemporal loads/stores in the streaming kernels */
+    QSV_OPT_NONTEMPORAL = 4 /* 1 (default): nontemporal loads/stores in the streaming kernels */
 };
 
 typedef struct qsv_state qsv_state;
@@ -145,6 +145,9 @@ int qsv_tensor_apply_axis(int device, void *hip_stream, const void *dev_in, void
 /* ---- timing on the state's stream (HIP events), for bench.py's roofline figures ----------- */
 int qsv_timer_start(qsv_state *st);
 int qsv_timer_stop(qsv_state *st, float *elapsed_ms); /* records, synchronises the event, returns ms */
+/* Name of the gate kernel the most recent qsv_apply_* call launched on this state, spelled as rocprofv3
+ * prints it (e.g. "k_dense<1, 0, 1, true>"); "" if none.  Lets bench.py attribute its event timings. */
+int qsv_last_kernel(const qsv_state *st, char *buf, size_t buf_len);
 /* Non-blocking marks: record HIP event number `slot` (0 <= slot < 16384) on the state's stream;
  * qsv_event_elapsed_ms waits for mark `slot_b` and returns the device time between two marks. */
 int qsv_event_record(qsv_state *st, int slot);

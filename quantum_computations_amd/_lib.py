@@ -63,6 +63,7 @@ SIGNATURES: dict[str, list] = {
                               C.c_uint64, C.c_void_p],
     "qsv_timer_start": [_state_p],
     "qsv_timer_stop": [_state_p, C.POINTER(C.c_float)],
+    "qsv_last_kernel": [_state_p, C.c_char_p, C.c_size_t],
     "qsv_event_record": [_state_p, C.c_int],
     "qsv_event_elapsed_ms": [_state_p, C.c_int, C.c_int, C.POINTER(C.c_float)],
 }

@@ -105,11 +105,17 @@ bool matrix_equals(int D, const double *m, const double *ref_real) {
     return true;
 }
 
+// A control only saves HBM traffic when skipping its control = 0 amplitudes skips whole 128-byte lines, i.e.
+// when the control bit is >= 3 (8 amplitudes).  Below that a "controlled" kernel still moves every line and
+// the predicated lanes cost time (sweep: 2.0 ms vs 1.35 ms at n = 28), so such controls are folded back into
+// the matrix and the gate runs at full traffic.
+constexpr int QSV_MIN_CTRL_BIT = 3;
+
 // 1-qubit diagonal with the traffic-saving special cases: d0 == 1 touches only the bit = 1 half.
 int diag_1q_bits(qsv_state *st, int bit, const double d[4]) {
     if (st->specialize && is_one(d[0], d[1])) {
         if (is_one(d[2], d[3])) return QSV_OK;  // identity
-        return qsvk_phase(st, 1, &bit, d[2], d[3]);
+        if (bit >= QSV_MIN_CTRL_BIT) return qsvk_phase(st, 1, &bit, d[2], d[3]);
     }
     return qsvk_diag(st, 1, &bit, 0, nullptr, d);
 }
@@ -117,19 +123,46 @@ int diag_1q_bits(qsv_state *st, int bit, const double d[4]) {
 int diag_2q_bits(qsv_state *st, int b0, int b1, const double d[8]) {
     if (st->specialize) {
         const bool one0 = is_one(d[0], d[1]), one1 = is_one(d[2], d[3]), one2 = is_one(d[4], d[5]);
+        const bool c0 = b0 >= QSV_MIN_CTRL_BIT, c1 = b1 >= QSV_MIN_CTRL_BIT;
         if (one0 && one1 && one2) {  // controlled phase: CZ touches a quarter of the register
             if (is_one(d[6], d[7])) return QSV_OK;
-            const int both[2] = {b0, b1};
-            return qsvk_phase(st, 2, both, d[6], d[7]);
-        }
-        if (one0 && one1) return qsvk_diag(st, 1, &b1, 1, &b0, d + 4);  // control on leg 0
-        if (one0 && one2 && d[2] == d[6] && d[3] == d[7]) {
+            const double dd[4] = {1.0, 0.0, d[6], d[7]};
+            if (c0 && c1) {
+                const int both[2] = {b0, b1};
+                return qsvk_phase(st, 2, both, d[6], d[7]);
+            }
+            if (c0) return qsvk_diag(st, 1, &b1, 1, &b0, dd);  // half traffic: control on the wide bit
+            if (c1) return qsvk_diag(st, 1, &b0, 1, &b1, dd);
+        } else if (one0 && one1 && c0) {
+            return qsvk_diag(st, 1, &b1, 1, &b0, d + 4);  // control on leg 0
+        } else if (one0 && one2 && d[2] == d[6] && d[3] == d[7]) {
             const double dd[4] = {1.0, 0.0, d[2], d[3]};  // acts on leg 1 only
             return diag_1q_bits(st, b1, dd);
         }
     }
     const int bits[2] = {b0, b1};
     return qsvk_diag(st, 2, bits, 0, nullptr, d);
+}
+
+// Controlled 2x2 gate; one narrow control (bit < 3) is folded into a 4x4 matrix (see QSV_MIN_CTRL_BIT).
+int controlled_1q_bits(qsv_state *st, int nctrl, const int *cbits, int tbit, const double u[8]) {
+    int fold = -1;
+    for (int i = 0; i < nctrl && st->n >= QSV_LANE_BITS; ++i)
+        if (cbits[i] < QSV_MIN_CTRL_BIT) fold = i;
+    if (fold < 0) return qsvk_dense(st, 1, &tbit, nctrl, cbits, u);
+    double m[32] = {0};
+    m[0] = 1.0;            // |00><00|
+    m[2 * (1 * 4 + 1)] = 1.0;  // |01><01|
+    for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 2; ++c) {
+            m[2 * ((2 + r) * 4 + 2 + c)] = u[2 * (r * 2 + c)];
+            m[2 * ((2 + r) * 4 + 2 + c) + 1] = u[2 * (r * 2 + c) + 1];
+        }
+    std::vector<int> rest;
+    for (int i = 0; i < nctrl; ++i)
+        if (i != fold) rest.push_back(cbits[i]);
+    const int bits[2] = {cbits[fold], tbit};
+    return qsvk_dense(st, 2, bits, static_cast<int>(rest.size()), rest.data(), m);
 }
 
 }  // namespace
@@ -331,7 +364,7 @@ int qsv_apply_2q(qsv_state *st, int q0, int q1, const double m[32]) {
             }
         if (ctl0) {
             const double u[8] = {m[20], m[21], m[22], m[23], m[28], m[29], m[30], m[31]};
-            return qsvk_dense(st, 1, &bits[1], 1, &bits[0], u);
+            if (bits[0] >= QSV_MIN_CTRL_BIT) return qsvk_dense(st, 1, &bits[1], 1, &bits[0], u);
         }
     }
     return qsvk_dense(st, 2, bits, 0, nullptr, m);
@@ -362,7 +395,7 @@ int qsv_apply_cx(qsv_state *st, int control, int target) {
     QSV_HIP(hipSetDevice(st->device));
     const int cbit = bit_of(st, control), tbit = bit_of(st, target);
     static const double X[8] = {0, 0, 1, 0, 1, 0, 0, 0};
-    return qsvk_dense(st, 1, &tbit, 1, &cbit, X);
+    return controlled_1q_bits(st, 1, &cbit, tbit, X);
 }
 
 int qsv_apply_swap(qsv_state *st, int q0, int q1) {
@@ -392,7 +425,7 @@ int qsv_apply_controlled_1q(qsv_state *st, int n_controls, const int *controls, 
     const int tbit = bit_of(st, target);
     if (st->n < QSV_LANE_BITS && n_controls + 1 > QSV_MAX_K)
         return qsv_fail(QSV_EINVAL, "too many controls for a tiny register");
-    return qsvk_dense(st, 1, &tbit, n_controls, cbits.data(), m);
+    return controlled_1q_bits(st, n_controls, cbits.data(), tbit, m);
 }
 
 int qsv_apply_mcphase(qsv_state *st, int n_qubits, const int *qubits, double re, double im) {
@@ -403,7 +436,19 @@ int qsv_apply_mcphase(qsv_state *st, int n_qubits, const int *qubits, double re,
     QSV_HIP(hipSetDevice(st->device));
     std::vector<int> cbits(n_qubits);
     for (int i = 0; i < n_qubits; ++i) cbits[i] = bit_of(st, qubits[i]);
-    return qsvk_phase(st, n_qubits, cbits.data(), re, im);
+    // narrow bits (< 3) become diagonal targets instead of controls (QSV_MIN_CTRL_BIT)
+    std::vector<int> wide, narrow;
+    for (int b : cbits) (b >= QSV_MIN_CTRL_BIT || st->n < QSV_LANE_BITS ? wide : narrow).push_back(b);
+    if (narrow.empty()) return qsvk_phase(st, n_qubits, cbits.data(), re, im);
+    while (narrow.size() > 2) {
+        wide.push_back(narrow.back());
+        narrow.pop_back();
+    }
+    double d[8] = {1, 0, 1, 0, 1, 0, 1, 0};
+    const int k = static_cast<int>(narrow.size());
+    d[2 * ((1 << k) - 1)] = re;
+    d[2 * ((1 << k) - 1) + 1] = im;
+    return qsvk_diag(st, k, narrow.data(), static_cast<int>(wide.size()), wide.data(), d);
 }
 
 int qsv_apply_kq(qsv_state *st, int k, const int *qubits, const double *m) {
@@ -626,6 +671,13 @@ int qsv_timer_stop(qsv_state *st, float *elapsed_ms) {
     QSV_HIP(hipEventRecord(st->ev_stop, st->stream));
     QSV_HIP(hipEventSynchronize(st->ev_stop));
     QSV_HIP(hipEventElapsedTime(elapsed_ms, st->ev_start, st->ev_stop));
+    return QSV_OK;
+}
+
+int qsv_last_kernel(const qsv_state *st, char *buf, size_t buf_len) {
+    if (!valid(st) || !buf || buf_len == 0) return qsv_fail(QSV_EINVAL, "null pointer");
+    std::strncpy(buf, st->last_kernel, buf_len - 1);
+    buf[buf_len - 1] = '\0';
     return QSV_OK;
 }
 

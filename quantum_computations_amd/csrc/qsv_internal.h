@@ -69,7 +69,8 @@ struct qsv_state {
     int specialize = 1;
     int unroll = 0;
     int grid_cap = 0;
-    int nontemporal = 0;
+    int nontemporal = 1;
+    char last_kernel[96] = "";        // name of the most recent gate kernel launched (qsv_last_kernel)
 };
 
 constexpr int QSV_REDUCE_BLOCKS = 1024;

@@ -78,7 +78,7 @@ __device__ __forceinline__ uint64_t deposit(uint64_t w, const Args &g) {
 // Dense 1- and 2-qubit gates (optionally controlled).
 // ----------------------------------------------------------------------------------------------------
 template <int KH, int KL, int U, bool NT>
-__global__ __launch_bounds__(QSV_BLOCK) void k_dense(amp_t *__restrict__ a, const GateArgs g) {
+__device__ __forceinline__ void dense_body(amp_t *__restrict__ a, const GateArgs &g) {
     constexpr int NH = 1 << KH, NL = 1 << KL, D = NH * NL;
     const int lane = threadIdx.x & 63;
     const bool lane_ok = (static_cast<uint32_t>(lane) & g.lane_ctrl) == g.lane_ctrl;
@@ -146,6 +146,19 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_dense(amp_t *__restrict__ a, cons
             }
         }
     }
+}
+
+// k_dense: every amplitude is read and written once (2 * 16 * 2^n bytes).  k_dense_ctrl: the same body on a
+// sub-space (controlled gates, SWAP as a pair exchange) -- a separate symbol so that profiles keep the
+// full-traffic launches apart from the reduced-traffic ones.
+template <int KH, int KL, int U, bool NT>
+__global__ __launch_bounds__(QSV_BLOCK) void k_dense(amp_t *__restrict__ a, const GateArgs g) {
+    dense_body<KH, KL, U, NT>(a, g);
+}
+
+template <int KH, int KL, int U, bool NT>
+__global__ __launch_bounds__(QSV_BLOCK) void k_dense_ctrl(amp_t *__restrict__ a, const GateArgs g) {
+    dense_body<KH, KL, U, NT>(a, g);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -462,15 +475,37 @@ int sum_partials(qsv_state *st, int blocks, double *x, double *y) {
 
 template <int KH, int KL, int U>
 void launch_dense_nt(qsv_state *st, const GateArgs &g, int grid) {
-    if (st->nontemporal)
-        hipLaunchKernelGGL((k_dense<KH, KL, U, true>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g);
-    else
-        hipLaunchKernelGGL((k_dense<KH, KL, U, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g);
+    const bool sub = g.nins > KH || g.lane_ctrl != 0;
+    const dim3 gd(grid), bd(QSV_BLOCK);
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense%s<%d, %d, %d, %s>", sub ? "_ctrl" : "", KH, KL, U,
+             st->nontemporal ? "true" : "false");
+    if (st->nontemporal) {
+        if (sub) hipLaunchKernelGGL((k_dense_ctrl<KH, KL, U, true>), gd, bd, 0, st->stream, st->data, g);
+        else hipLaunchKernelGGL((k_dense<KH, KL, U, true>), gd, bd, 0, st->stream, st->data, g);
+    } else {
+        if (sub) hipLaunchKernelGGL((k_dense_ctrl<KH, KL, U, false>), gd, bd, 0, st->stream, st->data, g);
+        else hipLaunchKernelGGL((k_dense<KH, KL, U, false>), gd, bd, 0, st->stream, st->data, g);
+    }
+}
+
+// Work items in flight per thread, from the MI355X sweeps under profiles/ (n = 28): with nontemporal
+// accesses one item per thread streams best (6.0-6.4 TB/s) until the pair stride reaches 16 MiB (bit 20),
+// where four items per thread hold 5.8 TB/s and one item drops to 5.4.
+template <int KH, int KL>
+int default_unroll(const GateArgs &g) {
+    if (KH == 0) return KL == 2 ? 2 : 1;
+    bool far = false;  // a pair stride of 16 MiB .. 512 MiB (bits 20..25)
+    for (int h = 1; h < (1 << KH); h <<= 1) {
+        int bit = 0;
+        while ((g.hoff[h] >> bit) > 1) ++bit;
+        far = far || (bit >= 20 && bit <= 25);
+    }
+    return far ? 4 : 1;
 }
 
 template <int KH, int KL>
 int launch_dense(qsv_state *st, const GateArgs &g) {
-    int U = st->unroll > 0 ? st->unroll : (8 >> KH);  // 8 x 16-byte loads in flight per lane
+    int U = st->unroll > 0 ? st->unroll : default_unroll<KH, KL>(g);
     // never more unrolling than there is work for one tile
     while (U > 1 && g.W < static_cast<uint64_t>(QSV_BLOCK) * U) U >>= 1;
     const int grid = grid_for(g.W, QSV_BLOCK * U, st->grid_cap);
@@ -480,6 +515,27 @@ int launch_dense(qsv_state *st, const GateArgs &g) {
         case 4: launch_dense_nt<KH, KL, 4>(st, g, grid); break;
         default: launch_dense_nt<KH, KL, 8>(st, g, grid); break;
     }
+    return check_launch();
+}
+
+int launch_diag(qsv_state *st, const DiagArgs &g) {
+    int U = st->unroll > 0 ? st->unroll : 1;
+    while (U > 1 && g.W < static_cast<uint64_t>(QSV_BLOCK) * U) U >>= 1;
+    const dim3 gd(grid_for(g.W, QSV_BLOCK * U, st->grid_cap)), bd(QSV_BLOCK);
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_diag<%d, %s>%s", U, st->nontemporal ? "true" : "false",
+             (g.nins > 0 || g.lane_ctrl) ? " [sub-space]" : "");
+#define QSV_LAUNCH_DIAG(UU)                                                                  \
+    if (st->nontemporal)                                                                      \
+        hipLaunchKernelGGL((k_diag<UU, true>), gd, bd, 0, st->stream, st->data, g);            \
+    else                                                                                      \
+        hipLaunchKernelGGL((k_diag<UU, false>), gd, bd, 0, st->stream, st->data, g)
+    switch (U) {
+        case 1: QSV_LAUNCH_DIAG(1); break;
+        case 2: QSV_LAUNCH_DIAG(2); break;
+        case 4: QSV_LAUNCH_DIAG(4); break;
+        default: QSV_LAUNCH_DIAG(8); break;
+    }
+#undef QSV_LAUNCH_DIAG
     return check_launch();
 }
 
@@ -572,6 +628,7 @@ int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user) {
         g.leg_pos[j] = static_cast<uint8_t>(bits[j]);
     }
     const int grid = grid_for(g.W, QSV_BLOCK, 4096);
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_generic<%d>", k);
     switch (k) {
         case 1: hipLaunchKernelGGL((k_generic<1>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
         case 2: hipLaunchKernelGGL((k_generic<2>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
@@ -663,22 +720,7 @@ int qsvk_diag(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits
         g.b0 = bits[0];
         g.b1 = k == 2 ? bits[1] : -1;
         std::memcpy(g.d, d_user, sizeof(double) * (2 << k));
-        int U = st->unroll > 0 ? st->unroll : 8;
-        while (U > 1 && g.W < static_cast<uint64_t>(QSV_BLOCK) * U) U >>= 1;
-        const int grid = grid_for(g.W, QSV_BLOCK * U, st->grid_cap);
-#define QSV_LAUNCH_DIAG(UU)                                                                                       \
-    if (st->nontemporal)                                                                                          \
-        hipLaunchKernelGGL((k_diag<UU, true>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g);           \
-    else                                                                                                          \
-        hipLaunchKernelGGL((k_diag<UU, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g)
-        switch (U) {
-            case 1: QSV_LAUNCH_DIAG(1); break;
-            case 2: QSV_LAUNCH_DIAG(2); break;
-            case 4: QSV_LAUNCH_DIAG(4); break;
-            default: QSV_LAUNCH_DIAG(8); break;
-        }
-#undef QSV_LAUNCH_DIAG
-        return check_launch();
+        return launch_diag(st, g);
     }
     // table path (k > 2 or tiny register); controls are folded into the table
     std::vector<int> legs(cbits, cbits + nctrl);
@@ -704,6 +746,7 @@ int qsvk_diag(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits
     // the two pageable-source copies above are staged before return (HIP semantics), so `table` may die
     QSV_HIP(hipStreamSynchronize(st->stream));
     const int grid = grid_for(st->amps, QSV_BLOCK, 4096);
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_diag_table");
     hipLaunchKernelGGL(k_diag_table, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, K, dpos,
                        st->dev_matrix);
     return check_launch();
@@ -726,16 +769,7 @@ int qsvk_phase(qsv_state *st, int nctrl, const int *cbits, double re, double im)
     g.b1 = -1;
     g.d[0] = g.d[2] = re;
     g.d[1] = g.d[3] = im;
-    int U = st->unroll > 0 ? st->unroll : 8;
-    while (U > 1 && g.W < static_cast<uint64_t>(QSV_BLOCK) * U) U >>= 1;
-    const int grid = grid_for(g.W, QSV_BLOCK * U, st->grid_cap);
-    switch (U) {
-        case 1: hipLaunchKernelGGL((k_diag<1, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g); break;
-        case 2: hipLaunchKernelGGL((k_diag<2, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g); break;
-        case 4: hipLaunchKernelGGL((k_diag<4, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g); break;
-        default: hipLaunchKernelGGL((k_diag<8, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g); break;
-    }
-    return check_launch();
+    return launch_diag(st, g);
 }
 
 int qsvk_measure_probs(qsv_state *st, int bit, const double e0[4], const double e1[4], double *p0, double *p1) {

@@ -252,6 +252,12 @@ class DeviceState:
         return ms.value
 
 
+    def last_kernel(self) -> str:
+        """Name of the gate kernel the most recent apply launched, as rocprofv3 spells it."""
+        buf = C.create_string_buffer(128)
+        _lib.call("qsv_last_kernel", self._h, buf, 128)
+        return buf.value.decode()
+
     def event_record(self, slot: int) -> None:
         """Non-blocking HIP event mark number ``slot`` on the register's stream."""
         _lib.call("qsv_event_record", self._h, int(slot))

@@ -55,7 +55,7 @@ def main():
     u2, u4 = W.haar_unitary(2, rng), W.haar_unitary(4, rng)
 
     variants = [(0, 0, 0)] if args.quick else [(0, 0, 0), (1, 0, 0), (2, 0, 0), (4, 0, 0), (8, 0, 0), (0, 1, 0),
-                                                (0, 0, 2048), (0, 0, 4096), (0, 0, 16384)]
+                                                (1, 1, 0), (2, 1, 0), (4, 1, 0), (8, 1, 0), (1, 0, 65536)]
     emit("\n## dense 1q: GB/s by target bit (bit = n-1-q); columns = (unroll, nontemporal, grid cap)")
     emit("bit  " + "  ".join(f"u{u}/nt{nt}/g{g:<6d}" for u, nt, g in variants))
     rows = {}
@@ -70,7 +70,7 @@ def main():
     for bit in range(n):
         emit(f"{bit:3d}  " + "  ".join(f"{v:14.0f}" for v in rows[bit]))
     dev.set_option(_lib.OPT_UNROLL, 0)
-    dev.set_option(_lib.OPT_NONTEMPORAL, 0)
+    dev.set_option(_lib.OPT_NONTEMPORAL, 1)
     dev.set_option(_lib.OPT_GRID_CAP, 0)
 
     emit("\n## dense 2q: GB/s for (bit0, bit1) samples, default launch shape")
@@ -80,12 +80,31 @@ def main():
         ms = timed(dev, lambda: dev.apply_matrix(u4, [n - 1 - b0, n - 1 - b1]), args.reps)
         emit(f"({b0:2d},{b1:2d})  {gbytes / (ms * 1e-3):8.0f} GB/s   {ms:7.3f} ms")
     if not args.quick:
-        for u in (1, 2, 4):
-            dev.set_option(_lib.OPT_UNROLL, u)
-            for b0, b1 in [(10, 20), (2, 9), (0, 1)]:
+        emit("\n## dense 2q variants: GB/s; columns = (unroll, nontemporal)")
+        combos = [(u, nt) for nt in (0, 1) for u in (1, 2, 4)]
+        emit("pair     " + "  ".join(f"u{u}/nt{nt}" for u, nt in combos))
+        for b0, b1 in [(0, 1), (2, 9), (5, 6), (6, 7), (10, 20), (6, n - 1), (20, 25), (n - 2, n - 1), (13, 14)]:
+            vals = []
+            for u, nt in combos:
+                dev.set_option(_lib.OPT_UNROLL, u)
+                dev.set_option(_lib.OPT_NONTEMPORAL, nt)
                 ms = timed(dev, lambda: dev.apply_matrix(u4, [n - 1 - b0, n - 1 - b1]), args.reps)
-                emit(f"unroll {u} ({b0:2d},{b1:2d})  {gbytes / (ms * 1e-3):8.0f} GB/s")
+                vals.append(gbytes / (ms * 1e-3))
+            emit(f"({b0:2d},{b1:2d})  " + "  ".join(f"{v:6.0f}" for v in vals))
+        emit("\n## general diagonal 1q variants: GB/s; columns = (unroll, nontemporal)")
+        combos = [(u, nt) for nt in (0, 1) for u in (1, 2, 4, 8)]
+        emit("bit   " + "  ".join(f"u{u}/nt{nt}" for u, nt in combos))
+        dd = np.exp(1j * rng.uniform(0, 6.28, 2))
+        for bit in (0, 12, n - 1):
+            vals = []
+            for u, nt in combos:
+                dev.set_option(_lib.OPT_UNROLL, u)
+                dev.set_option(_lib.OPT_NONTEMPORAL, nt)
+                ms = timed(dev, lambda: dev.apply_diagonal(dd, [n - 1 - bit]), args.reps)
+                vals.append(gbytes / (ms * 1e-3))
+            emit(f"{bit:3d}   " + "  ".join(f"{v:6.0f}" for v in vals))
         dev.set_option(_lib.OPT_UNROLL, 0)
+        dev.set_option(_lib.OPT_NONTEMPORAL, 1)
 
     emit("\n## specialised kernels (credited with the full algorithmic bytes): ms and equivalent GB/s")
     d1 = np.exp(1j * rng.uniform(0, 6.28, 2))
