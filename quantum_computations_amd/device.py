@@ -195,6 +195,11 @@ class DeviceState:
         _lib.call("qsv_apply_mcphase", self._h, len(qubits), _ints(qubits), phase.real, phase.imag)
         return self
 
+    def apply_scale(self, factor: complex) -> "DeviceState":
+        factor = complex(factor)
+        _lib.call("qsv_scale", self._h, factor.real, factor.imag)
+        return self
+
     def permute(self, new_ordering) -> "DeviceState":
         _lib.call("qsv_permute", self._h, _ints(new_ordering))
         return self

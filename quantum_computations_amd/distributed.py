@@ -1,0 +1,382 @@
+"""Registers sharded over the GPUs of one node: one process per GPU, ``torch.distributed`` (RCCL over xGMI).
+
+The 2^n amplitudes are split by their top index bits: with G = 2^g ranks, rank r holds the contiguous shard of
+amplitudes whose g most significant *physical* index bits spell r (reference qubits 0..g-1 at start, because
+the reference is big-endian -- SURVEY.md 8e).  A gate is then one of:
+
+* **local** -- every leg sits on a local bit: each rank runs the single-GPU kernel on its shard, no traffic;
+* **block-diagonal in a remote leg** (diagonal gates, controls: Z, RZ, T, CZ, the control of CX, ...): the rank's
+  own bit value selects the sub-block to apply locally -- still no traffic;
+* **mixing a remote leg** (H, X, a Haar gate, the target of CX on a remote qubit): that qubit is first made
+  local by swapping its physical bit with the top local bit -- a pairwise exchange of half a shard with rank
+  ``r ^ bit`` (``batch_isend_irecv`` -> ncclSend/ncclRecv grouped) -- after which the gate is local.  The swap is
+  *not* undone: the register keeps a logical -> physical bit map, so later gates on that qubit stay local.
+
+The class is written against a small "local engine" interface (the methods of ``DeviceState`` it uses) and
+against torch tensors for the exchange, so the sharding logic runs unchanged on CPU tensors with the ``gloo``
+backend in the tests (with a test-owned engine) and on HBM tensors with ``nccl`` in production.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _default_engine_factory(device: int):
+    import torch
+
+    from .device import DeviceState
+
+    def make(buf, n_local):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        return DeviceState.view(n_local, buf.data_ptr(), buf.numel(), device=device, stream=stream, keepalive=buf)
+    return make
+
+
+def _leg_is_block_diagonal(m: np.ndarray, k: int, leg: int) -> bool:
+    """True if the 2^k x 2^k matrix never maps leg = a to leg = b != a (so the leg's bit value is conserved)."""
+    t = m.reshape((2,) * (2 * k))
+    idx01 = [slice(None)] * (2 * k)
+    idx01[leg], idx01[k + leg] = 0, 1
+    idx10 = list(idx01)
+    idx10[leg], idx10[k + leg] = 1, 0
+    return not np.any(t[tuple(idx01)]) and not np.any(t[tuple(idx10)])
+
+
+def _restrict_leg(m: np.ndarray, k: int, leg: int, value: int) -> np.ndarray:
+    """Sub-block of a matrix that is block-diagonal in ``leg``, for leg bit = ``value``: a 2^(k-1) matrix."""
+    t = m.reshape((2,) * (2 * k))
+    idx = [slice(None)] * (2 * k)
+    idx[leg], idx[k + leg] = value, value
+    return np.ascontiguousarray(t[tuple(idx)]).reshape(1 << (k - 1), 1 << (k - 1))
+
+
+class ShardedState:
+    """n-qubit complex128 register sharded over ``world`` ranks (a power of two)."""
+
+    ndim = 1
+
+    def __init__(self, n_qubits: int, buf, engine_factory, group=None):
+        import torch.distributed as dist
+
+        self._dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.g = (self.world - 1).bit_length()
+        if 1 << self.g != self.world:
+            raise ValueError("the register shards over a power-of-two number of ranks")
+        if n_qubits < self.g + 1:
+            raise ValueError("need at least one local qubit per rank")
+        self.n = n_qubits
+        self.n_local = n_qubits - self.g
+        self.buf = buf                                    # torch tensor, 2^n_local complex128, this rank's shard
+        self._factory = engine_factory
+        self.local = engine_factory(buf, self.n_local)
+        self._scratch = None                              # half-shard receive buffer, allocated on first exchange
+        # physical bit position of each logical bit (logical bit b = reference qubit n-1-b)
+        self.phys = list(range(n_qubits))
+        self.exchanges = 0                                # half-shard exchanges performed (for reports)
+        self.bytes_sent = 0
+
+    # ---- construction ---------------------------------------------------------------------------
+    @classmethod
+    def random(cls, n_qubits: int, seed: int, device: int = 0, group=None) -> "ShardedState":
+        """Normalised pseudo-random register generated shard by shard on the GPUs (counter-based)."""
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size(group)
+        n_local = n_qubits - (world - 1).bit_length()
+        buf = torch.empty(1 << n_local, dtype=torch.complex128, device=torch.device("cuda", device))
+        st = cls(n_qubits, buf, _default_engine_factory(device), group)
+        st.fill_random(seed)
+        return st
+
+    @classmethod
+    def zeros(cls, n_qubits: int, device: int = 0, group=None) -> "ShardedState":
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size(group)
+        n_local = n_qubits - (world - 1).bit_length()
+        buf = torch.zeros(1 << n_local, dtype=torch.complex128, device=torch.device("cuda", device))
+        st = cls(n_qubits, buf, _default_engine_factory(device), group)
+        if st.rank == 0:
+            st.local.set_basis(0)
+        return st
+
+    def fill_random(self, seed: int) -> None:
+        import torch
+
+        n2 = self.local.fill_random(seed, index_offset=self.rank << self.n_local, normalise=False)
+        self.local.apply_scale(1.0 / float(np.sqrt(self._allreduce_sum([n2])[0])))
+        self.phys = list(range(self.n))
+
+    # ---- bookkeeping ----------------------------------------------------------------------------
+    @property
+    def num_qubits(self) -> int:
+        return self.n
+
+    @property
+    def num_amps(self) -> int:
+        return 1 << self.n
+
+    @property
+    def shape(self):
+        return (self.num_amps,)
+
+    def _bit(self, qubit: int) -> int:
+        if not 0 <= qubit < self.n:
+            raise ValueError(f"qubit index {qubit} out of range for a {self.n}-qubit register")
+        return self.phys[self.n - 1 - qubit]
+
+    def _rank_bit(self, phys_bit: int) -> int:
+        return (self.rank >> (phys_bit - self.n_local)) & 1
+
+    def _local_qubit(self, phys_bit: int) -> int:
+        return self.n_local - 1 - phys_bit
+
+    def sync(self) -> None:
+        self.local.sync()
+
+    # ---- the exchange step ----------------------------------------------------------------------
+    def _swap_bits_local(self, bit_a: int, bit_b: int) -> None:
+        if bit_a == bit_b:
+            return
+        self.local.apply_swap(self._local_qubit(bit_a), self._local_qubit(bit_b))
+        ia, ib = self.phys.index(bit_a), self.phys.index(bit_b)
+        self.phys[ia], self.phys[ib] = bit_b, bit_a
+
+    # The three collectives the register needs.  Kept as small methods so that a test can stage them through
+    # host memory (gloo on a box with fewer GPUs than ranks); production uses them as written, on RCCL.
+    def _exchange(self, send, recv, peer: int) -> None:
+        """Simultaneous send of ``send`` to ``peer`` and receive of ``recv`` from it (grouped ncclSend/ncclRecv)."""
+        dist = self._dist
+        peer_global = dist.get_global_rank(self.group, peer) if self.group is not None else peer
+        ops = [dist.P2POp(dist.isend, send, peer_global, self.group),
+               dist.P2POp(dist.irecv, recv, peer_global, self.group)]
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()
+
+    def _allreduce_sum(self, values: list[float]) -> list[float]:
+        import torch
+
+        t = torch.tensor(values, dtype=torch.float64, device=self.buf.device)
+        self._dist.all_reduce(t, group=self.group)
+        return [float(v) for v in t.cpu()]
+
+    def _allgather_shards(self):
+        import torch
+
+        shards = [torch.empty_like(self.buf) for _ in range(self.world)]
+        self._dist.all_gather(shards, self.buf.contiguous(), group=self.group)
+        return torch.cat(shards).cpu().numpy()
+
+    def _localise(self, gbit: int, avoid: set[int]) -> int:
+        """Swap global physical bit ``gbit`` with the top local bit (kept clear of ``avoid``); returns the
+        local bit the qubit now occupies.  One half-shard send + receive with rank ``r ^ (1 << (gbit - n_local))``."""
+        import torch
+
+        top = self.n_local - 1
+        if top in avoid:                        # the top local bit is a leg of this gate: park it lower first
+            free = max(b for b in range(self.n_local) if b not in avoid)
+            self._swap_bits_local(top, free)
+        half = 1 << top
+        mine = self._rank_bit(gbit)
+        peer = self.rank ^ (1 << (gbit - self.n_local))
+        # the (G = mine, L = mine) half stays; the (G = mine, L = 1 - mine) half goes to the peer, whose
+        # (G = 1 - mine, L = mine) half takes its place
+        give = self.buf[(1 - mine) * half:(2 - mine) * half]
+        if self._scratch is None or self._scratch.numel() < half:
+            self._scratch = torch.empty(half, dtype=self.buf.dtype, device=self.buf.device)
+        recv = self._scratch[:half]
+        self._exchange(give, recv, peer)
+        give.copy_(recv)
+        self.exchanges += 1
+        self.bytes_sent += half * 16
+        # the logical bit that lived on `top` now lives on `gbit`, and vice versa
+        i_top, i_g = self.phys.index(top), self.phys.index(gbit)
+        self.phys[i_top], self.phys[i_g] = gbit, top
+        return top
+
+    # ---- gates ----------------------------------------------------------------------------------
+    #
+    # Every decision that changes the data layout (which qubits get localised) depends only on the gate and
+    # on the logical -> physical map, never on this rank's own bits: all ranks take the same path through
+    # _localise, so the map stays identical everywhere and every exchange finds its partner.  Only the
+    # *local* work after that depends on the rank (which sub-block of a conserved remote leg applies).
+    def _localise_all(self, qubits: list[int], keep_local: list[int]) -> None:
+        """Make every qubit of ``qubits`` local; ``keep_local`` are other legs that must not be displaced."""
+        for q in qubits:
+            b = self._bit(q)
+            if b >= self.n_local:
+                avoid = {self._bit(x) for x in list(qubits) + list(keep_local) if self._bit(x) < self.n_local}
+                self._localise(b, avoid)
+
+    def apply_matrix(self, matrix, indices) -> "ShardedState":
+        """``U_full @ ket`` for a 2^k x 2^k matrix on reference qubits ``indices`` (``Gate.apply``)."""
+        qubits = [int(q) for q in indices]
+        k = len(qubits)
+        m = np.asarray(matrix, dtype=np.complex128)
+        if m.shape != (1 << k, 1 << k):
+            raise ValueError("Dimensions of given matrix is not compatible with number of indices.")
+        if len(set(qubits)) != k:
+            raise ValueError("Indices must be distinct.")
+        for q in qubits:
+            self._bit(q)
+        conserved = [_leg_is_block_diagonal(m, k, j) for j in range(k)]
+        mixing = [q for q, c in zip(qubits, conserved) if not c]
+        if len(mixing) > self.n_local:
+            raise ValueError("gate has more mixing legs than a shard has qubits")
+        # 1) remote legs the gate mixes: bring those qubits into the shard (one half-shard exchange each)
+        self._localise_all(mixing, [q for q in qubits if q not in mixing])
+        # 2) remote legs whose bit value the gate conserves (diagonal legs, controls): this rank's sub-block
+        j = 0
+        while j < len(qubits):
+            b = self._bit(qubits[j])
+            if b >= self.n_local:
+                m = _restrict_leg(m, len(qubits), j, self._rank_bit(b))
+                del qubits[j]
+            else:
+                j += 1
+        if not qubits:
+            if m[0, 0] != 1.0:
+                self.local.apply_scale(complex(m[0, 0]))
+            return self
+        if np.array_equal(m, np.identity(m.shape[0])):
+            return self
+        self.local.apply_matrix(m, [self._local_qubit(self._bit(q)) for q in qubits])
+        return self
+
+    def apply_diagonal(self, diagonal, indices) -> "ShardedState":
+        return self.apply_matrix(np.diag(np.asarray(diagonal, dtype=np.complex128)), indices)
+
+    def apply_cx(self, control: int, target: int) -> "ShardedState":
+        return self.apply_controlled(np.array([[0, 1], [1, 0]], dtype=complex), [control], target)
+
+    def apply_swap(self, q0: int, q1: int) -> "ShardedState":
+        """SWAP is a relabelling of the logical -> physical map: no amplitude moves."""
+        self._bit(q0), self._bit(q1)
+        if q0 == q1:
+            raise ValueError("Indices must be distinct.")
+        b0, b1 = self.n - 1 - q0, self.n - 1 - q1
+        self.phys[b0], self.phys[b1] = self.phys[b1], self.phys[b0]
+        return self
+
+    def apply_mcphase(self, qubits, phase: complex) -> "ShardedState":
+        """Multiply the amplitudes whose ``qubits`` are all 1 by ``phase``: never any traffic."""
+        bits = [self._bit(int(q)) for q in qubits]
+        if any(self._rank_bit(b) == 0 for b in bits if b >= self.n_local):
+            return self
+        local = [self._local_qubit(b) for b in bits if b < self.n_local]
+        if local:
+            self.local.apply_mcphase(local, phase)
+        else:
+            self.local.apply_scale(complex(phase))
+        return self
+
+    def apply_controlled(self, matrix, controls, target: int) -> "ShardedState":
+        """2x2 ``matrix`` on ``target`` where all ``controls`` are 1.  Controls never move data; the target is
+        localised (by every rank, see above) only if the matrix mixes it."""
+        controls = [int(c) for c in controls]
+        target = int(target)
+        if len(set(controls + [target])) != len(controls) + 1:
+            raise ValueError("Indices must be distinct.")
+        u = np.asarray(matrix, dtype=np.complex128).reshape(2, 2)
+        diagonal = u[0, 1] == 0 and u[1, 0] == 0
+        for q in controls + [target]:
+            self._bit(q)
+        if not diagonal:
+            self._localise_all([target], controls)
+        cbits = [self._bit(c) for c in controls]
+        if any(self._rank_bit(b) == 0 for b in cbits if b >= self.n_local):
+            return self
+        local_c = [self._local_qubit(b) for b in cbits if b < self.n_local]
+        tb = self._bit(target)
+        if tb >= self.n_local:                       # diagonal on a remote target: a phase picked by our bit
+            phase = u[self._rank_bit(tb), self._rank_bit(tb)]
+            if phase != 1.0:
+                if local_c:
+                    self.local.apply_mcphase(local_c, phase)
+                else:
+                    self.local.apply_scale(complex(phase))
+        elif local_c:
+            self.local.apply_controlled(u, local_c, self._local_qubit(tb))
+        else:
+            self.local.apply_matrix(u, [self._local_qubit(tb)])
+        return self
+
+    def insert(self, index: int, amplitudes):
+        raise NotImplementedError("Insert on a sharded register is not built yet: start from ShardedState.zeros")
+
+    # ---- measurement ----------------------------------------------------------------------------
+    def measure_probs(self, index: int, eig0, eig1) -> tuple[float, float]:
+        import torch
+
+        b = self._bit(index)
+        if b >= self.n_local:
+            b = self._localise(b, set())
+        p0, p1 = self._allreduce_sum(list(self.local.measure_probs(self._local_qubit(b), eig0, eig1)))
+        return p0, p1
+
+    def collapse(self, index: int, eig, scale: float) -> "ShardedState":
+        """Project reference qubit ``index`` on ``eig`` and drop it: every shard shrinks by half."""
+        b = self._bit(index)
+        if b >= self.n_local:
+            b = self._localise(b, set())
+        self.local.collapse(self._local_qubit(b), eig, scale)
+        # physical bits above b move down by one; the measured logical bit disappears
+        lb = self.phys.index(b)
+        del self.phys[lb]
+        self.phys = [p - 1 if p > b else p for p in self.phys]
+        self.n -= 1
+        self.n_local -= 1
+        self.buf = self.buf[: 1 << self.n_local]
+        return self
+
+    # ---- read-out -------------------------------------------------------------------------------
+    def norm2(self) -> float:
+        return self._allreduce_sum([self.local.norm2()])[0]
+
+    def _physical_index(self, logical_index: int) -> int:
+        out = 0
+        for lb in range(self.n):
+            if (logical_index >> lb) & 1:
+                out |= 1 << self.phys[lb]
+        return out
+
+    def probabilities(self, indices) -> np.ndarray:
+        """|amplitude|^2 at the given (logical, reference-ordered) basis indices, on every rank."""
+        import torch
+
+        out = np.zeros(len(indices), dtype=np.float64)
+        mine, where = [], []
+        for j, idx in enumerate(indices):
+            p = self._physical_index(int(idx))
+            if p >> self.n_local == self.rank:
+                mine.append(p & ((1 << self.n_local) - 1))
+                where.append(j)
+        if mine:
+            out[where] = self.local.probabilities(mine)
+        return np.array(self._allreduce_sum(out.tolist()), dtype=np.float64)
+
+    def to_numpy(self) -> np.ndarray:
+        """The whole ket in reference order, on every rank (tests and small registers only)."""
+        import torch
+
+        self.local.sync()
+        physical = self._allgather_shards()
+        # physical[axis for bit p] -> logical: logical bit lb reads physical bit phys[lb]
+        t = physical.reshape((2,) * self.n)                      # axis a <-> physical bit n-1-a
+        axes = [self.n - 1 - self.phys[self.n - 1 - a] for a in range(self.n)]   # logical axis a <- physical axis
+        return np.ascontiguousarray(t.transpose(axes)).reshape(-1)
+
+    # ---- timing passthrough (bench.py) ------------------------------------------------------------
+    def event_record(self, slot: int) -> None:
+        self.local.event_record(slot)
+
+    def event_elapsed_ms(self, a: int, b: int) -> float:
+        return self.local.event_elapsed_ms(a, b)
+
+    def last_kernel(self) -> str:
+        return self.local.last_kernel()

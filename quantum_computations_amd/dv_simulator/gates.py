@@ -22,6 +22,11 @@ from ..device import DeviceState
 REPR_DIGITS = 5
 
 
+def is_device_register(state) -> bool:
+    """A register that lives in HBM: a ``DeviceState`` or a ``distributed.ShardedState`` (same gate methods)."""
+    return isinstance(state, DeviceState) or (not isinstance(state, np.ndarray) and hasattr(state, "apply_matrix"))
+
+
 def _as_result_dtype(values: np.ndarray, *operands, padded: bool = True) -> np.ndarray:
     """Cast the complex128 device result to the dtype NumPy promotion gives the reference's ``@``.
 
@@ -73,7 +78,7 @@ class Gate:
             raise ValueError(f"Matrix representation not given for {self}.")
         if self.matrix.shape[0] != self.matrix.shape[1]:
             raise ValueError("new_ordering must be a permutation of all qubits")  # as expand_gate would
-        if isinstance(state, DeviceState):
+        if is_device_register(state):
             return state.apply_matrix(self.matrix, self.indices)
         state = np.asarray(state)
         if state.ndim == 1:
@@ -180,7 +185,7 @@ class Insert(SingleQubitGate):
     def apply(self, state):
         new_qubit = self.matrix[0, :]
         index = self.indices[0]
-        if isinstance(state, DeviceState):
+        if is_device_register(state):
             return state.insert(index, new_qubit)
         state = np.asarray(state)
         dev = DeviceState.from_numpy(state)
@@ -218,7 +223,7 @@ class M(SingleQubitGate):
         return int(s)
 
     def apply(self, state):
-        if isinstance(state, DeviceState):
+        if is_device_register(state):
             return state, self._measure(state)
         dev = DeviceState.from_numpy(np.asarray(state))
         s = self._measure(dev)

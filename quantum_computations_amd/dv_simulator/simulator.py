@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .gates import Gate, Insert, M
+from .gates import Gate, Insert, M, is_device_register
 from .states import State
 from .numpy_quantum import tensor
 from ..device import DeviceState
@@ -36,7 +36,7 @@ def parse_state(state) -> np.ndarray | DeviceState:
     :class:`State` becomes their tensor product (``simulator.py:19-28``)."""
     if state is None:
         return np.ones((1,))
-    if isinstance(state, (np.ndarray, DeviceState)):
+    if isinstance(state, np.ndarray) or is_device_register(state):
         return state
     if isinstance(state, list) and all(isinstance(item, State) for item in state):
         return tensor(*(s.get() for s in state))

@@ -1,0 +1,183 @@
+"""Worker of the multi-process tests: run under ``python -m torch.distributed.run`` (one process per rank).
+
+    dist_worker.py --backend gloo            # CPU tensors, oracle-backed local engine (tests/oracle_engine.py)
+    dist_worker.py --backend nccl            # HBM tensors, HIP kernels (one GPU per rank)
+
+Every rank builds the same circuits, runs them on a ``ShardedState`` and compares the gathered ket with the
+CPU oracle's result for the unsharded register.  Exits non-zero on any mismatch.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent))
+sys.path.insert(0, str(HERE))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from oracle import dv_oracle as O  # noqa: E402
+from quantum_computations_amd import workloads as W  # noqa: E402
+from quantum_computations_amd.distributed import ShardedState  # noqa: E402
+from quantum_computations_amd.dv_simulator import gates as G  # noqa: E402
+from quantum_computations_amd.dv_simulator.simulator import Simulator  # noqa: E402
+
+TOL = 1e-12
+
+
+class HostStagedShardedState(ShardedState):
+    """The production register (HBM shards, HIP kernels) with the three collectives staged through host memory
+    over gloo: lets several ranks share ONE GPU in a test, where RCCL refuses duplicate devices."""
+
+    def _exchange(self, send, recv, peer):
+        send_h, recv_h = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+        ops = [dist.P2POp(dist.isend, send_h, peer), dist.P2POp(dist.irecv, recv_h, peer)]
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()
+        recv.copy_(recv_h)
+
+    def _allreduce_sum(self, values):
+        t = torch.tensor(values, dtype=torch.float64)
+        dist.all_reduce(t)
+        return [float(v) for v in t]
+
+    def _allgather_shards(self):
+        mine = self.buf.cpu().contiguous()
+        shards = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(shards, mine)
+        return torch.cat(shards).numpy()
+
+
+def make_state(n, ket, backend, device):
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n_local = n - (world - 1).bit_length()
+    shard = np.ascontiguousarray(ket[rank << n_local:(rank + 1) << n_local])
+    if backend == "gloo":
+        import oracle_engine
+        buf = torch.from_numpy(shard.copy())
+        return ShardedState(n, buf, oracle_engine.factory)
+    from quantum_computations_amd.distributed import _default_engine_factory
+    buf = torch.from_numpy(shard.copy()).to(torch.device("cuda", device))
+    cls = HostStagedShardedState if backend == "gloo-gpu" else ShardedState
+    return cls(n, buf, _default_engine_factory(device))
+
+
+def check(name, got, want, tol=TOL):
+    err = float(np.max(np.abs(got - want)))
+    if not err < tol:
+        raise AssertionError(f"[rank {dist.get_rank()}] {name}: max abs err {err:.3e}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--qubits", type=int, default=9)
+    args = ap.parse_args()
+    device = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.backend == "nccl":
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    else:
+        if args.backend == "gloo-gpu":
+            device = 0                       # every rank shares the one GPU of the test box
+            torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+    world, rank = dist.get_world_size(), dist.get_rank()
+    g = (world - 1).bit_length()
+    n = args.qubits
+    rng = np.random.default_rng(5)
+
+    # 1. the cfg2/cfg3 generator: 1- and 2-qubit gates on arbitrary (also remote) qubits
+    for seed in (11, 12):
+        ops = W.random_circuit(n, 80, seed)
+        ket = W.random_ket(n, seed)
+        st = make_state(n, ket, args.backend, device)
+        for gate in W.to_gates(ops):
+            out = gate.apply(st)
+            assert out is st
+        want, _ = O.run_circuit(ops, ket)
+        check(f"random circuit seed {seed}", st.to_numpy(), want)
+        assert st.exchanges > 0, "a depth-80 circuit must touch a remote qubit"
+        assert abs(st.norm2() - 1.0) < 1e-12
+
+    # 2. the remote-qubit CX mix of BASELINE config 3: global->local, local->global, global->global
+    ket = W.random_ket(n, 3)
+    st = make_state(n, ket, args.backend, device)
+    pairs = [(0, n - 1), (n - 1, 0), (n - 2, n - 3)]
+    if g >= 2:
+        pairs += [(0, 1), (1, 0)]
+    pairs += [(0, n - 1), (n - 1, 0)]          # again, after the layout has changed
+    want = ket
+    cx = W.op("CX", 0, 1)["matrix"]
+    before = st.exchanges
+    for c, t in pairs:
+        G.CX(c, t).apply(st)
+        want = O.apply_gate(want, cx, [c, t])
+    check("CX mix", st.to_numpy(), want)
+    exchanges_cx = st.exchanges - before
+    # diagonal gates and controls on remote qubits never exchange anything
+    before = st.exchanges
+    for q in range(n):
+        G.T(q).apply(st)
+        want = O.apply_gate(want, G.T(q).matrix, [q])
+        G.CZ(q, (q + 3) % n).apply(st)
+        want = O.apply_gate(want, G.CZ(0, 1).matrix, [q, (q + 3) % n])
+    st.apply_mcphase(list(range(0, n, 2)), np.exp(0.7j))
+    d = np.ones(1 << len(range(0, n, 2)), dtype=complex)
+    d[-1] = np.exp(0.7j)
+    want = O.apply_gate(want, np.diag(d), list(range(0, n, 2)))
+    assert st.exchanges == before, "diagonal gates must not communicate"
+    check("diagonal gates on remote qubits", st.to_numpy(), want)
+    # SWAP is a relabelling
+    G.SWAP(0, n - 1).apply(st)
+    want = O.apply_gate(want, G.SWAP(0, 1).matrix, [0, n - 1])
+    assert st.exchanges == before
+    check("swap relabel", st.to_numpy(), want)
+    # controlled gates with remote controls / remote target
+    u = W.haar_unitary(2, rng)
+    for controls, target in [([0, n - 1], 3), ([2, 3], 0), ([0], 1), ([n - 1, n - 2, 1], 0)]:
+        st.apply_controlled(u, controls, target)
+        full = np.identity(1 << (len(controls) + 1), dtype=complex)
+        full[-2:, -2:] = u
+        want = O.apply_gate(want, full, controls + [target])
+    check("controlled gates", st.to_numpy(), want)
+    probe = [0, 1, (1 << n) - 1, 37 % (1 << n), 1 << (n - 1)]
+    check("probabilities", st.probabilities(probe), np.abs(want[probe]) ** 2, 1e-14)
+
+    # 3. measurement (forced outcomes) of a remote and a local qubit, through the Simulator
+    ket = W.random_ket(n, 4)
+    st = make_state(n, ket, args.backend, device)
+    circuit = [G.H(0), G.CX(0, n - 1), G.M(0, 0.4, 1.1, result=1), G.H(n - 3), G.MZ(n - 2, result=0), G.H(0)]
+    sim = Simulator(circuit)
+    out = sim.run(st)
+    ops = [W.op("H", 0), W.op("CX", 0, n - 1),
+           {"name": "M", "indices": [0], "theta": 0.4, "phi": 1.1, "result": 1, "matrix": None},
+           W.op("H", n - 3), {"name": "M", "indices": [n - 2], "theta": 0.0, "phi": 0.0, "result": 0, "matrix": None},
+           W.op("H", 0)]
+    want, results = O.run_circuit(ops, ket)
+    assert sim.results == results == [1, 0]
+    assert out.num_qubits == n - 2
+    check("measurement", out.to_numpy(), want)
+
+    # 4. counter-based fill: the sharded register equals the unsharded one
+    if args.backend == "gloo":
+        import oracle_engine
+        st = make_state(n, np.zeros(1 << n, dtype=complex), args.backend, device)
+        st.fill_random(77)
+        whole = oracle_engine.counter_normal(77, 0, 1 << n)
+        check("fill_random", st.to_numpy(), whole / np.linalg.norm(whole), 1e-13)
+
+    dist.barrier()
+    if rank == 0:
+        print(f"dist_worker ok: world={world} backend={args.backend} n={n} cx_exchanges={exchanges_cx}")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

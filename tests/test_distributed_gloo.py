@@ -1,0 +1,39 @@
+"""The N > 1 path on CPU: world_size 2 and 4 with the ``gloo`` backend (tests/dist_worker.py).
+
+What is under test is ``quantum_computations_amd.distributed.ShardedState`` -- the logical->physical qubit map,
+the half-shard exchange over ``torch.distributed`` and the no-traffic handling of diagonal legs and controls.
+The per-shard gate arithmetic is supplied by a test double (tests/oracle_engine.py); on the GPU box the same
+worker runs with HIP kernels (tests/test_gpu_parity.py::test_sharded_state_on_one_gpu).
+"""
+from __future__ import annotations
+
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+HERE = Path(__file__).resolve().parent
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_workers(world: int, *extra: str, timeout: int = 600) -> str:
+    env = dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(HERE / "dist_worker.py"), *extra]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert proc.returncode == 0, proc.stdout[-3000:] + "\n" + proc.stderr[-3000:]
+    return proc.stdout
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_register_matches_oracle(world):
+    out = run_workers(world, "--backend", "gloo", "--qubits", "9")
+    assert f"dist_worker ok: world={world}" in out

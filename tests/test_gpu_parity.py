@@ -375,6 +375,14 @@ def test_full_size_28q_round_trip_and_known_answers():
     assert abs(out_state.probabilities([(1 << (n - 1)) - 1])[0] - 1.0) < 1e-12
 
 
+# ---- sharded registers with the real HIP engine (ranks share the one GPU; collectives staged over gloo) -------
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_state_on_one_gpu(world):
+    from test_distributed_gloo import run_workers
+    out = run_workers(world, "--backend", "gloo-gpu", "--qubits", "12")
+    assert f"dist_worker ok: world={world} backend=gloo-gpu" in out
+
+
 # ---- d-level modes --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n_modes,d", [(1, 32), (3, 8), (4, 5), (3, 32), (2, 70)])
 def test_mode_gates_against_tensordot(n_modes, d):
