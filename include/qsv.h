@@ -137,6 +137,18 @@ int qsv_apply_mode1(qsv_state *st, int mode, const double *m /* d x d */);
 int qsv_apply_mode1_diag(qsv_state *st, int mode, const double *diag /* d */);
 int qsv_apply_mode2(qsv_state *st, int mode0, int mode1, const double *m /* d^2 x d^2 */);
 int qsv_apply_mode2_diag(qsv_state *st, int mode0, int mode1, const double *diag /* d^2 */);
+/* Sparse two-mode map: output plane point (i0, i1) = sum_k vals[(i0*d+i1)*nnz + k] * input plane point
+ * cols[(i0*d+i1)*nnz + k] (= j0*d+j1; negative = unused slot).  The bilinear resampling of the (q1, q2)
+ * plane that BS and CX do per bond pair with RegularGridInterpolator (cv_simulator/gates.py:74-80,187-189)
+ * is nnz = 4; SWAP (gates.py:48-55) is nnz = 1. */
+int qsv_apply_mode2_gather(qsv_state *st, int mode0, int mode1, int nnz, const int32_t *cols, const double *vals);
+/* Homodyne read-out (Mq.apply, cv_simulator/gates.py:90-117): probs[j] = sum over the other modes of
+ * |amp|^2 at level j of `mode` (the diagonal of partial_density_mps, mps.py:176-190, without the dq factors);
+ * project keeps level `level` of `mode`, multiplies by `scale` and removes the mode. */
+int qsv_mode_marginal(qsv_state *st, int mode, double *probs /* d */);
+int qsv_mode_project(qsv_state *st, int mode, int level, double scale);
+/* New mode with amplitudes vec[0..d) (complex) at position `mode` (Insert.apply, gates.py:24-45). */
+int qsv_mode_insert(qsv_state *st, int mode, const double *vec /* d */);
 /* out[l, :, r] = M @ in[l, :, r] on a raw (L, d_in, R) device tensor -> (L, d_out, R): the exact
  * tensordot+moveaxis of whittaker_shannon / rotation (cv_simulator/utils.py:9-39) on an MPS site. */
 int qsv_tensor_apply_axis(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L,

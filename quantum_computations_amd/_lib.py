@@ -59,6 +59,10 @@ SIGNATURES: dict[str, list] = {
     "qsv_apply_mode1_diag": [_state_p, C.c_int, C.c_void_p],
     "qsv_apply_mode2": [_state_p, C.c_int, C.c_int, C.c_void_p],
     "qsv_apply_mode2_diag": [_state_p, C.c_int, C.c_int, C.c_void_p],
+    "qsv_apply_mode2_gather": [_state_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "qsv_mode_marginal": [_state_p, C.c_int, C.c_void_p],
+    "qsv_mode_project": [_state_p, C.c_int, C.c_int, C.c_double],
+    "qsv_mode_insert": [_state_p, C.c_int, C.c_void_p],
     "qsv_tensor_apply_axis": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                               C.c_uint64, C.c_void_p],
     "qsv_timer_start": [_state_p],
@@ -75,6 +79,35 @@ class QsvError(RuntimeError):
     """HIP / device failure reported by libqsv.so (QSV_EHIP)."""
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """Make libqsv.so and PyTorch use ONE HIP runtime, whatever the import order.
+
+    The PyTorch-ROCm wheel bundles its own ``libamdhip64.so`` (SONAME ``libamdhip64.so.7``) and asks the loader for
+    it by the unversioned file name, while libqsv.so needs ``libamdhip64.so.7``.  If libqsv.so is loaded first it
+    pulls in /opt/rocm's copy, torch then loads its bundled copy as a second runtime, and that one finds no GPU
+    ("No HIP GPUs are available").  Pre-loading torch's copy here (without importing torch) lets the SONAME match
+    satisfy libqsv.so and the file identity match satisfy torch.  Without torch installed nothing happens and
+    libqsv.so uses the system runtime.
+    """
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    candidate = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+    if candidate.exists():
+        try:
+            C.CDLL(str(candidate), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> C.CDLL:
     """Load libqsv.so once.  Raises if it has not been built -- the product has no other execution path."""
     global _lib
@@ -85,6 +118,7 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build the HIP library first (python -m quantum_computations_amd.build, or "
             "__graft_entry__.build()).  quantum_computations_amd has no CPU fallback."
         )
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(str(LIB_PATH))
     lib.qsv_version.restype = C.c_int
     lib.qsv_version.argtypes = []

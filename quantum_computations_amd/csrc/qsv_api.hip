@@ -569,7 +569,7 @@ int qsv_inner(qsv_state *a, qsv_state *b, double *re, double *im) {
 // ---- d-level modes ----------------------------------------------------------------------------------
 
 static int qudit_amps(int n_modes, int d, uint64_t *amps) {
-    if (n_modes < 1 || d < 2) return qsv_fail(QSV_EINVAL, "need n_modes >= 1 and d >= 2");
+    if (n_modes < 0 || d < 2) return qsv_fail(QSV_EINVAL, "need n_modes >= 0 and d >= 2");
     uint64_t a = 1;
     for (int i = 0; i < n_modes; ++i) {
         if (a > (1ull << 40) / static_cast<uint64_t>(d)) return qsv_fail(QSV_EINVAL, "register too large");
@@ -645,6 +645,42 @@ int qsv_apply_mode2_diag(qsv_state *st, int mode0, int mode1, const double *diag
     if (rc) return rc;
     QSV_HIP(hipSetDevice(st->device));
     return qsvq_mode2(st, mode0, mode1, diag, true);
+}
+
+int qsv_apply_mode2_gather(qsv_state *st, int mode0, int mode1, int nnz, const int32_t *cols, const double *vals) {
+    if (!valid(st) || !cols || !vals) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (nnz < 1 || nnz > 64) return qsv_fail(QSV_EINVAL, "nnz must be in 1..64");
+    const int ms[2] = {mode0, mode1};
+    int rc = check_modes(st, 2, ms);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvq_mode2_gather(st, mode0, mode1, nnz, cols, vals);
+}
+
+int qsv_mode_marginal(qsv_state *st, int mode, double *probs) {
+    if (!valid(st) || !probs) return qsv_fail(QSV_EINVAL, "null pointer");
+    int rc = check_modes(st, 1, &mode);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvq_mode_marginal(st, mode, probs);
+}
+
+int qsv_mode_project(qsv_state *st, int mode, int level, double scale) {
+    if (!valid(st)) return qsv_fail(QSV_EINVAL, "null state");
+    int rc = check_modes(st, 1, &mode);
+    if (rc) return rc;
+    if (level < 0 || level >= st->d) return qsv_fail(QSV_EINVAL, "level out of range");
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvq_mode_project(st, mode, level, scale);
+}
+
+int qsv_mode_insert(qsv_state *st, int mode, const double *vec) {
+    if (!valid(st) || !vec) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (st->kind != 1) return qsv_fail(QSV_ESTATE, "this call needs a qudit register");
+    if (mode < 0 || mode > st->n) return qsv_fail(QSV_EINVAL, "Cannot insert mode at this index");
+    if (st->amps > (1ull << 40) / static_cast<uint64_t>(st->d)) return qsv_fail(QSV_EINVAL, "register too large");
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvq_mode_insert(st, mode, vec);
 }
 
 int qsv_tensor_apply_axis(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d_in,

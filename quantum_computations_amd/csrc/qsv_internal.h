@@ -105,5 +105,9 @@ int qsvk_scratch(qsv_state *st, uint64_t amps, amp_t **out);  // temporary devic
 
 int qsvq_mode1(qsv_state *st, int mode, const double *m, bool diag);
 int qsvq_mode2(qsv_state *st, int mode0, int mode1, const double *m, bool diag);
+int qsvq_mode2_gather(qsv_state *st, int mode0, int mode1, int nnz, const int32_t *cols, const double *vals);
+int qsvq_mode_marginal(qsv_state *st, int mode, double *probs);
+int qsvq_mode_project(qsv_state *st, int mode, int level, double scale);
+int qsvq_mode_insert(qsv_state *st, int mode, const double *vec);
 int qsvq_tensor_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in,
                      uint64_t d_out, uint64_t R, const double *m_host);

@@ -617,6 +617,7 @@ int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user) {
     int rc = qsvk_ensure_matrix(st, bytes);
     if (rc) return rc;
     QSV_HIP(hipMemcpyAsync(st->dev_matrix, m_user, bytes, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));  // m_user is the caller's (pageable) memory: see qsvq_mode1
     GenericArgs g;
     std::memset(&g, 0, sizeof(g));
     g.K = k;

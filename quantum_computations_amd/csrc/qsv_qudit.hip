@@ -6,6 +6,7 @@
 
 #include "qsv_internal.h"
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -131,6 +132,83 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_mode2_diag(amp_t *__restrict__ a,
     }
 }
 
+// Two-mode sparse row operator ("gather"): every output plane point (i0, i1) is a weighted sum of `nnz` input plane
+// points.  This is the MI355X form of the reference's per-bond-pair RegularGridInterpolator loop for BS / CX
+// (bilinear resampling of the (q1, q2) plane: 4 weights per point, cv_simulator/gates.py:74-80,187-189), and of
+// SWAP (nnz = 1).  View (L, d, Mid, d, R); cols/vals are indexed [(i0 * d + i1) * nnz + k], col = j0 * d + j1.
+__global__ __launch_bounds__(QSV_BLOCK) void k_mode2_gather(const amp_t *__restrict__ in, amp_t *__restrict__ out,
+                                                           uint64_t L, int d, uint64_t Mid, uint64_t R, int nnz,
+                                                           const int32_t *__restrict__ cols,
+                                                           const double *__restrict__ vals) {
+    const uint64_t total = L * d * Mid * d * R;
+    const uint64_t s1 = R, sm = R * d, s0 = R * d * Mid, sl = R * d * Mid * d;
+    for (uint64_t o = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t r = o % R, i1 = (o / s1) % d, m = (o / sm) % Mid, i0 = (o / s0) % d, l = o / sl;
+        const uint64_t base = l * sl + m * sm + r;
+        const size_t row = (i0 * d + i1) * static_cast<size_t>(nnz);
+        amp_t acc = {0.0, 0.0};
+        for (int k = 0; k < nnz; ++k) {
+            const int32_t c = cols[row + k];
+            if (c < 0) continue;  // padding entry
+            const cplx w = {vals[2 * (row + k)], vals[2 * (row + k) + 1]};
+            acc = cfma(w, in[base + (c / d) * s0 + (c % d) * s1], acc);
+        }
+        out[o] = acc;
+    }
+}
+
+// probs[j] += sum over everything but the mode axis of |a[l, j, r]|^2.  One workgroup per (j, slice of l):
+// deterministic two-level sum (block partials [j][slice] summed on the host in index order).
+__global__ __launch_bounds__(QSV_BLOCK) void k_mode_marginal(const amp_t *__restrict__ a, uint64_t L, int d, uint64_t R,
+                                                            int slices, double *__restrict__ partials) {
+    __shared__ double red[QSV_BLOCK / 64];
+    const int j = blockIdx.x / slices, slice = blockIdx.x % slices;
+    const uint64_t fibre = L * R;  // number of (l, r) pairs
+    const uint64_t lo = fibre * slice / slices, hi = fibre * (slice + 1) / slices;
+    double s = 0.0;
+    for (uint64_t f = lo + threadIdx.x; f < hi; f += blockDim.x) {
+        const uint64_t l = f / R, r = f % R;
+        const amp_t v = a[(l * d + j) * R + r];
+        s += v.x * v.x + v.y * v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < QSV_BLOCK / 64; ++i) t += red[i];
+        partials[blockIdx.x] = t;
+    }
+}
+
+// out[l, r] = scale * a[l, level, r]: the register after a homodyne outcome (cv_simulator/gates.py:108-115).
+__global__ __launch_bounds__(QSV_BLOCK) void k_mode_project(const amp_t *__restrict__ a, amp_t *__restrict__ out,
+                                                           uint64_t L, int d, uint64_t R, int level, double scale) {
+    const uint64_t total = L * R;
+    for (uint64_t o = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t l = o / R, r = o % R;
+        amp_t v = a[(l * d + level) * R + r];
+        v.x *= scale;
+        v.y *= scale;
+        out[o] = v;
+    }
+}
+
+// out[l, j, r] = vec[j] * a[l, r]: a new mode in a product state (cv_simulator/gates.py:24-35 without the SVD).
+__global__ __launch_bounds__(QSV_BLOCK) void k_mode_insert(const amp_t *__restrict__ a, amp_t *__restrict__ out,
+                                                          uint64_t L, int d, uint64_t R,
+                                                          const double *__restrict__ vec) {
+    const uint64_t total = L * d * R;
+    for (uint64_t o = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t r = o % R, j = (o / R) % d, l = o / (R * d);
+        out[o] = cmul(cplx{vec[2 * j], vec[2 * j + 1]}, a[l * R + r]);
+    }
+}
+
 int check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return qsv_fail(QSV_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -191,6 +269,9 @@ int qsvq_mode1(qsv_state *st, int mode, const double *m, bool diag) {
     int rc = qsvk_ensure_matrix(st, bytes);
     if (rc) return rc;
     QSV_HIP(hipMemcpyAsync(st->dev_matrix, m, bytes, hipMemcpyHostToDevice, st->stream));
+    // the caller's buffer is pageable and may be freed as soon as we return: HIP does not promise to have
+    // staged an async pageable copy by then, so wait for it here (a few microseconds next to a full pass)
+    QSV_HIP(hipStreamSynchronize(st->stream));
     if (diag) {
         const int grid = grid_of(st->amps, QSV_BLOCK * 4, 1 << 16);
         hipLaunchKernelGGL(k_axis_diag, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps,
@@ -260,6 +341,125 @@ int qsvq_mode2(qsv_state *st, int mode0, int mode1, const double *m, bool diag) 
         return rc;
     }
     return adopt(st, fresh);
+}
+
+int qsvq_mode2_gather(qsv_state *st, int mode0, int mode1, int nnz, const int32_t *cols, const double *vals) {
+    const uint64_t d = st->d, d2 = d * d;
+    const int a = mode0 < mode1 ? mode0 : mode1, b = mode0 < mode1 ? mode1 : mode0;
+    const uint64_t L = ipow(d, a), Mid = ipow(d, b - a - 1), R = ipow(d, st->n - 1 - b);
+    // kernel order is (earlier axis, later axis); transpose rows and columns when mode0 is the later one
+    std::vector<int32_t> c(d2 * nnz);
+    std::vector<double> v(2 * d2 * nnz);
+    for (uint64_t i0 = 0; i0 < d; ++i0)
+        for (uint64_t i1 = 0; i1 < d; ++i1)
+            for (int k = 0; k < nnz; ++k) {
+                const uint64_t src = (i0 * d + i1) * nnz + k;
+                const uint64_t dst = (mode0 < mode1 ? (i0 * d + i1) : (i1 * d + i0)) * nnz + k;
+                int32_t col = cols[src];
+                if (col >= static_cast<int32_t>(d2)) return qsv_fail(QSV_EINVAL, "gather column out of range");
+                if (col >= 0 && mode0 > mode1) col = static_cast<int32_t>((col % d) * d + col / d);
+                c[dst] = col;
+                v[2 * dst] = vals[2 * src];
+                v[2 * dst + 1] = vals[2 * src + 1];
+            }
+    const size_t vbytes = sizeof(double) * v.size(), cbytes = sizeof(int32_t) * c.size();
+    int rc = qsvk_ensure_matrix(st, vbytes + cbytes);
+    if (rc) return rc;
+    int32_t *dcols = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(st->dev_matrix) + vbytes);
+    QSV_HIP(hipMemcpyAsync(st->dev_matrix, v.data(), vbytes, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipMemcpyAsync(dcols, c.data(), cbytes, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));  // c and v die at return
+    amp_t *fresh = nullptr;
+    rc = qsvk_scratch(st, st->amps, &fresh);
+    if (rc) return rc;
+    const int grid = grid_of(st->amps, QSV_BLOCK, 1 << 16);
+    hipLaunchKernelGGL(k_mode2_gather, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, L,
+                       static_cast<int>(d), Mid, R, nnz, dcols, st->dev_matrix);
+    rc = check_launch();
+    if (rc) {
+        (void)hipFree(fresh);
+        return rc;
+    }
+    return adopt(st, fresh);
+}
+
+int qsvq_mode_marginal(qsv_state *st, int mode, double *probs) {
+    const uint64_t d = st->d, R = ipow(d, st->n - 1 - mode), L = ipow(d, mode);
+    int slices = static_cast<int>(std::min<uint64_t>(std::max<uint64_t>(1, (L * R) / (QSV_BLOCK * 8)), 256));
+    while (static_cast<uint64_t>(slices) * d > (1u << 20)) slices = (slices + 1) / 2;
+    const size_t bytes = sizeof(double) * d * slices;
+    int rc = qsvk_ensure_matrix(st, bytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mode_marginal, dim3(static_cast<unsigned>(d * slices)), dim3(QSV_BLOCK), 0, st->stream,
+                       st->data, L, static_cast<int>(d), R, slices, st->dev_matrix);
+    rc = check_launch();
+    if (rc) return rc;
+    std::vector<double> host(d * slices);
+    QSV_HIP(hipMemcpyAsync(host.data(), st->dev_matrix, bytes, hipMemcpyDeviceToHost, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));
+    for (uint64_t j = 0; j < d; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < slices; ++k) s += host[j * slices + k];
+        probs[j] = s;
+    }
+    return QSV_OK;
+}
+
+// Replace the register by `fresh` holding new_amps amplitudes (the mode count changed).
+static int adopt_resized(qsv_state *st, amp_t *fresh, uint64_t new_amps) {
+    if (st->owns_data) {
+        QSV_HIP(hipStreamSynchronize(st->stream));
+        QSV_HIP(hipFree(st->data));
+        st->data = fresh;
+        st->capacity = new_amps;
+    } else {
+        QSV_HIP(hipMemcpyAsync(st->data, fresh, sizeof(amp_t) * new_amps, hipMemcpyDeviceToDevice, st->stream));
+        QSV_HIP(hipStreamSynchronize(st->stream));
+        QSV_HIP(hipFree(fresh));
+    }
+    st->amps = new_amps;
+    return QSV_OK;
+}
+
+int qsvq_mode_project(qsv_state *st, int mode, int level, double scale) {
+    const uint64_t d = st->d, R = ipow(d, st->n - 1 - mode), L = ipow(d, mode);
+    amp_t *fresh = nullptr;
+    int rc = qsvk_scratch(st, L * R, &fresh);
+    if (rc) return rc;
+    const int grid = grid_of(L * R, QSV_BLOCK * 4, 1 << 16);
+    hipLaunchKernelGGL(k_mode_project, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, L,
+                       static_cast<int>(d), R, level, scale);
+    rc = check_launch();
+    if (rc) {
+        (void)hipFree(fresh);
+        return rc;
+    }
+    st->n -= 1;
+    return adopt_resized(st, fresh, L * R);
+}
+
+int qsvq_mode_insert(qsv_state *st, int mode, const double *vec) {
+    const uint64_t d = st->d, R = ipow(d, st->n - mode), L = ipow(d, mode);  // the register has st->n modes now
+    const uint64_t out_amps = st->amps * d;
+    if (!st->owns_data && out_amps > st->capacity)
+        return qsv_fail(QSV_ENOMEM, "insert: the caller-owned buffer has no room for one more mode");
+    int rc = qsvk_ensure_matrix(st, sizeof(double) * 2 * d);
+    if (rc) return rc;
+    QSV_HIP(hipMemcpyAsync(st->dev_matrix, vec, sizeof(double) * 2 * d, hipMemcpyHostToDevice, st->stream));
+    amp_t *fresh = nullptr;
+    rc = qsvk_scratch(st, out_amps, &fresh);
+    if (rc) return rc;
+    const int grid = grid_of(out_amps, QSV_BLOCK * 4, 1 << 16);
+    hipLaunchKernelGGL(k_mode_insert, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, L,
+                       static_cast<int>(d), R, st->dev_matrix);
+    rc = check_launch();
+    if (rc) {
+        (void)hipFree(fresh);
+        return rc;
+    }
+    QSV_HIP(hipStreamSynchronize(st->stream));  // `vec` was read by the async copy
+    st->n += 1;
+    return adopt_resized(st, fresh, out_amps);
 }
 
 int qsvq_tensor_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in,

@@ -1,0 +1,106 @@
+"""Fock-truncated mode registers: BASELINE.json config 4 (6 modes x cutoff d = 32, squeezing + beam splitters).
+
+The reference has no Fock-basis operators at all (its ``S`` / ``Phase`` raise ``NotImplementedError``,
+``simulators/cv_simulator/gates.py:249-269``; the register is a position grid): **parity unpinned** for the matrices
+built here.  They are derived from the truncated ladder operator with ``scipy.linalg.expm`` on the host; what IS pinned
+is the contraction that applies them (``qsv_apply_mode1`` / ``qsv_apply_mode2`` == ``np.tensordot``).  The gate classes
+keep the cv_simulator API shape: ``SingleModeGate(index, ...)``, ``TwoModeGate(i, j, ...)`` (neighbours), ``apply(state)``.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.linalg import expm
+
+from ..device import QuditState
+from .gate_abc import SingleModeGate, TwoModeGate
+
+
+def annihilation(d: int) -> np.ndarray:
+    return np.diag(np.sqrt(np.arange(1, d)), 1).astype(np.complex128)
+
+
+def squeeze_matrix(d: int, r: float, angle: float = 0.0) -> np.ndarray:
+    """exp((z* a^2 - z a^dagger^2) / 2), z = r e^{i angle}, truncated to d levels."""
+    a = annihilation(d)
+    z = r * np.exp(1j * angle)
+    return expm(0.5 * (np.conj(z) * a @ a - z * a.conj().T @ a.conj().T))
+
+
+def phase_matrix(d: int, angle: float) -> np.ndarray:
+    return np.exp(-1j * angle * np.arange(d))          # diagonal: exp(-i angle n)
+
+
+def beamsplitter_matrix(d: int, theta: float, phi: float = 0.0) -> np.ndarray:
+    """exp(theta (e^{i phi} a b^dagger - e^{-i phi} a^dagger b)) on two d-level modes: a (d^2 x d^2) matrix, row / column
+    index n_a * d + n_b.  It conserves n_a + n_b, so every row has at most d non-zero entries."""
+    a = np.kron(annihilation(d), np.identity(d))
+    b = np.kron(np.identity(d), annihilation(d))
+    gen = theta * (np.exp(1j * phi) * a @ b.conj().T - np.exp(-1j * phi) * a.conj().T @ b)
+    return expm(gen)
+
+
+def sparse_rows(matrix: np.ndarray, tol: float = 0.0):
+    """Row-compressed (cols, vals) of a d^2 x d^2 matrix for ``qsv_apply_mode2_gather``; unused slots are -1 / 0."""
+    rows = matrix.shape[0]
+    mask = np.abs(matrix) > tol
+    nnz = max(1, int(mask.sum(axis=1).max()))
+    cols = np.full((rows, nnz), -1, dtype=np.int32)
+    vals = np.zeros((rows, nnz), dtype=np.complex128)
+    for r in range(rows):
+        idx = np.nonzero(mask[r])[0]
+        cols[r, : idx.size] = idx
+        vals[r, : idx.size] = matrix[r, idx]
+    return cols, vals
+
+
+class FockState:
+    """``n_modes`` modes truncated to ``d`` Fock levels each, dense complex128 in HBM, all starting in vacuum."""
+
+    def __init__(self, n_modes: int, d: int, device: int = 0):
+        self.reg = QuditState.zeros(n_modes, d, device)
+        self.d = d
+
+    def __len__(self):
+        return self.reg.dims[0]
+
+    def contract(self) -> np.ndarray:
+        return self.reg.to_numpy()
+
+    def norm(self) -> float:
+        return float(np.sqrt(self.reg.norm2()))
+
+
+class S(SingleModeGate):
+    def __init__(self, index, r: float, angle: float = 0.0, **kwargs):
+        super().__init__(index, arg=r, **kwargs)
+        self.angle = angle
+
+    def apply(self, state: FockState, **_):
+        r = -self.arg if self.dagger else self.arg
+        state.reg.apply_mode(squeeze_matrix(state.d, r, self.angle), self.index)
+
+
+class Phase(SingleModeGate):
+    def __init__(self, index, angle: float, **kwargs):
+        super().__init__(index, arg=angle, **kwargs)
+
+    def apply(self, state: FockState, **_):
+        state.reg.apply_mode(phase_matrix(state.d, -self.arg if self.dagger else self.arg), self.index)
+
+
+class BS(TwoModeGate):
+    """Beam splitter in the Fock basis.  ``dense=True`` applies the full d^2 x d^2 matrix; the default uses its
+    photon-number-conserving sparsity (<= d entries per row) through the gather kernel."""
+
+    def __init__(self, index1, index2, angle: float = np.pi / 4, *, dense: bool = False, **kwargs):
+        super().__init__(index1, index2, arg=angle, **kwargs)
+        self.dense = dense
+
+    def apply(self, state: FockState, **_):
+        theta = -self.arg if self.dagger else self.arg
+        m = beamsplitter_matrix(state.d, theta)
+        if self.dense:
+            state.reg.apply_two_mode(m, self.index1, self.index2)
+        else:
+            cols, vals = sparse_rows(m, tol=1e-300)
+            state.reg.apply_two_mode_gather(cols, vals, self.index1, self.index2)

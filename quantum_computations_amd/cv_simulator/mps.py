@@ -1,0 +1,126 @@
+"""Register of the CV simulator: a DENSE position-grid wavefunction in HBM behind the reference's ``MPS`` surface.
+
+The reference stores the state as a matrix-product state (``simulators/cv_simulator/mps.py:102-201``) and recompresses
+with an SVD after every two-mode gate.  The tensor-network compression is out of scope for this round (SURVEY.md row 7 /
+8f-3: a dense-LAPACK problem, not the bandwidth-bound gate path); what is in scope is the gate application itself, so
+``MPS`` here keeps the constructor, ``domain`` / ``diff``, ``len``, ``copy``, ``validate``, ``contract``, ``norm`` and
+``partial_density_mps`` of the reference class but holds the *contracted* tensor ``psi[q_0, ..., q_{m-1}]`` as a
+``QuditState`` (``d = len(domain)`` levels per mode).  Results equal the reference's with truncation disabled
+(``rel_err = 0``); ``svd_options`` are accepted and ignored.  Registers are limited by ``d^m * 16`` bytes of HBM.
+"""
+from __future__ import annotations
+
+import inspect
+from functools import reduce
+
+import numpy as np
+
+from ..device import QuditState
+
+
+def tensor_svd(tensor, left_indices, right_indices, *, max_bond_dim: int = np.inf, abs_err: float = 0,
+               rel_err: float = 1e-12, rng_seed: int = None):
+    raise NotImplementedError("MPS compression (truncated SVD) is not part of the MI355X gate path yet (SURVEY.md 8f-3)")
+
+
+# the keyword-only truncation options gates and the simulator accept (mps.py:99-100)
+SVD_OPTIONS = {name: p for name, p in inspect.signature(tensor_svd).parameters.items()
+               if p.kind == inspect.Parameter.KEYWORD_ONLY}
+
+
+class MPS:
+    def __init__(self, domain: np.ndarray, tensors: list[np.ndarray], *, device: int = 0):
+        """``tensors``: one entry per mode -- a wavefunction on ``domain`` (1-D) or an MPS site ``(chi_l, d, chi_r)``;
+        sites are contracted on the host (small registers) and the dense tensor is uploaded."""
+        self.domain: np.ndarray = domain
+        self._check_domain()
+        self.diff: float = abs(domain[-1] - domain[0]) / (len(domain) - 1)
+        sites = [np.asarray(t).reshape(1, -1, 1) if np.ndim(t) == 1 else np.asarray(t) for t in tensors]
+        self._check_sites(sites)
+        d = len(domain)
+        if sites:
+            dense = np.squeeze(reduce(lambda a, b: np.tensordot(a, b, axes=1), sites), axis=(0, -1))
+            self.reg = QuditState.from_numpy(np.ascontiguousarray(dense, dtype=np.complex128).reshape((d,) * len(sites)),
+                                             device)
+        else:
+            self.reg = QuditState.zeros(0, d, device)
+
+    @classmethod
+    def _wrap(cls, domain: np.ndarray, reg: QuditState) -> "MPS":
+        out = cls.__new__(cls)
+        out.domain = domain
+        out.diff = abs(domain[-1] - domain[0]) / (len(domain) - 1)
+        out.reg = reg
+        return out
+
+    # ---- container protocol ------------------------------------------------------------------------
+    def __len__(self):
+        return self.reg.dims[0]
+
+    def copy(self) -> "MPS":
+        return MPS._wrap(self.domain.copy(), self.reg.copy())
+
+    def shape(self):
+        n, d = self.reg.dims
+        return ("dense",) + (d,) * n
+
+    # ---- validation (mps.py:136-161) ----------------------------------------------------------------
+    def _check_domain(self):
+        if not isinstance(self.domain, np.ndarray) or self.domain.ndim != 1:
+            raise TypeError("Domain must be a 1D numpy array.")
+        if not np.allclose(np.diff(self.domain, 2), 0, atol=np.finfo(self.domain.dtype).eps ** 0.5):
+            raise ValueError("Domain is not an arithmetic progression.")
+
+    def _check_sites(self, sites):
+        for idx, t in enumerate(sites):
+            if t.ndim != 3:
+                raise ValueError(f"Tensor at index {idx} does not have exactly three axes.")
+            if t.shape[1] != len(self.domain):
+                raise ValueError(f"Tensor at index {idx} does not have the right physical dimension.")
+        if sites:
+            if sites[0].shape[0] != 1:
+                raise ValueError("Left-most tensor does not have a trivial left edge")
+            if sites[-1].shape[2] != 1:
+                raise ValueError("Right-most tensor does not have a trivial right edge")
+        for idx, (a, b) in enumerate(zip(sites, sites[1:])):
+            if a.shape[2] != b.shape[0]:
+                raise ValueError(f"Tensors at indices {idx} and {idx + 1} do not have compatible bond dimensions.")
+
+    def validate(self):
+        self._check_domain()
+        if not np.isclose(self.diff, abs(self.domain[-1] - self.domain[0]) / (len(self.domain) - 1)):
+            raise ValueError("Stored difference does not match current domain.")
+        if self.reg.dims[1] != len(self.domain):
+            raise ValueError("Register does not have the right physical dimension.")
+
+    # ---- read-out ---------------------------------------------------------------------------------------
+    def contract(self) -> np.ndarray:
+        """The dense tensor ``psi[q_0, ..., q_{m-1}]`` on the host (``MPS.contract``, mps.py:163-164)."""
+        return self.reg.to_numpy()
+
+    def norm(self) -> float:
+        """``sqrt(int |psi|^2)`` with the grid measure ``diff^m`` (mps.py:166-170)."""
+        return float(np.sqrt(self.reg.norm2() * self.diff ** len(self)))
+
+    def marginal(self, axis: int) -> np.ndarray:
+        """Diagonal of :meth:`partial_density_mps` -- the position density of mode ``axis`` -- computed on the device."""
+        if axis < 0 or axis >= len(self):
+            raise IndexError(f"axis={axis} out of bounds")
+        return self.reg.marginal(axis) * self.diff ** (len(self) - 1)
+
+    def partial_density_mps(self, axis: int) -> np.ndarray:
+        """Reduced density matrix of mode ``axis`` (mps.py:176-190).  Host contraction of the downloaded tensor:
+        for read-out of small registers; measurements use :meth:`marginal`, which stays on the GPU."""
+        if axis < 0 or axis >= len(self):
+            raise IndexError(f"axis={axis} out of bounds")
+        psi = np.moveaxis(self.contract(), axis, 0).reshape(len(self.domain), -1)
+        return (psi @ psi.conj().T) * self.diff ** (len(self) - 1)
+
+    @staticmethod
+    def fidelity(a: "MPS", b: "MPS") -> float:
+        """``|<a|b>|^2`` on a shared grid.  (The reference's version, mps.py:192-201, contracts ``a`` with itself
+        and never reads ``b``; this one computes what its docstring says.)"""
+        if len(a) != len(b):
+            raise ValueError("registers of different sizes")
+        overlap = np.vdot(a.contract(), b.contract()) * a.diff ** len(a)
+        return float(np.abs(overlap) ** 2)

@@ -23,7 +23,9 @@ def _cbuf(a, n_complex: int | None = None) -> np.ndarray:
 
 
 def _ptr(arr: np.ndarray) -> C.c_void_p:
-    return C.c_void_p(arr.ctypes.data)
+    # data_as() keeps a reference to the array on the returned pointer object, so a temporary passed as
+    # `_ptr(_cbuf(x))` stays alive for the duration of the foreign call (c_void_p(arr.ctypes.data) would not)
+    return arr.ctypes.data_as(C.c_void_p)
 
 
 def _ints(values) -> "C.Array[C.c_int]":
@@ -340,6 +342,46 @@ class QuditState:
         else:
             _lib.call("qsv_apply_mode2", self._h, int(mode0), int(mode1), _ptr(_cbuf(m, d ** 4)))
         return self
+
+    def apply_two_mode_gather(self, cols, vals, mode0: int, mode1: int) -> "QuditState":
+        """Sparse plane map: ``cols`` / ``vals`` of shape ``(d*d, nnz)`` (negative column = unused slot)."""
+        _, d = self.dims
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        vals = _cbuf(vals)
+        if cols.ndim != 2 or cols.shape[0] != d * d or vals.size != cols.size:
+            raise ValueError("cols and vals must both have shape (d*d, nnz)")
+        _lib.call("qsv_apply_mode2_gather", self._h, int(mode0), int(mode1), int(cols.shape[1]),
+                  C.c_void_p(cols.ctypes.data), _ptr(vals))
+        return self
+
+    def marginal(self, mode: int) -> np.ndarray:
+        """Sum of |amplitude|^2 over every other mode, per level of ``mode``."""
+        _, d = self.dims
+        out = np.empty(d, dtype=np.float64)
+        _lib.call("qsv_mode_marginal", self._h, int(mode), C.c_void_p(out.ctypes.data))
+        return out
+
+    def project(self, mode: int, level: int, scale: float) -> "QuditState":
+        """Keep level ``level`` of ``mode`` (times ``scale``) and remove the mode."""
+        _lib.call("qsv_mode_project", self._h, int(mode), int(level), float(scale))
+        return self
+
+    def insert(self, mode: int, amplitudes) -> "QuditState":
+        """New mode with the given ``d`` amplitudes at position ``mode`` (product with the rest)."""
+        _, d = self.dims
+        _lib.call("qsv_mode_insert", self._h, int(mode), _ptr(_cbuf(amplitudes, d)))
+        return self
+
+    def scale(self, factor: complex) -> "QuditState":
+        factor = complex(factor)
+        _lib.call("qsv_scale", self._h, factor.real, factor.imag)
+        return self
+
+    def copy(self) -> "QuditState":
+        n, d = self.dims
+        other = QuditState.zeros(n, d)
+        _lib.call("qsv_copy", other._h, self._h)
+        return other
 
     def norm2(self) -> float:
         v = C.c_double()

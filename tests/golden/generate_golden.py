@@ -334,9 +334,75 @@ def gen_cv():
     save("cv_operators.npz", cases=json.dumps(cases), **arrays)
 
 
+# (7b) cv_simulator: state preparation, homodyne measurements with forced results, Insert, the Simulator loop ----
+def gen_cv_extra():
+    from simulators.cv_simulator.simulator import Simulator as RefCVSimulator
+    from simulators.cv_simulator.states import State as RefCVState
+
+    arrays, cases = {}, []
+    qs = np.linspace(-9.0, 9.0, 64)
+    arrays["qs64"] = qs
+    for name, eps in [("VACUUM", None), ("GKP_ZERO", 0.2), ("GKP_ONE", 0.2), ("GKP_PLUS", 0.15), ("GKP_T", 0.1),
+                      ("GKP_H", 0.3), ("GKP_MINUS", 0.25), ("GKP_TDG", 0.2), ("QUNAUGHT", 0.2)]:
+        key = f"state_{name}"
+        arrays[key] = np.asarray(RefCVState[name].eval(qs, eps), dtype=np.complex128)
+        cases.append({"kind": "state", "key": key, "name": name, "eps": eps})
+
+    exact = {"rel_err": 0.0, "abs_err": 0.0}
+    rng = np.random.default_rng(17)
+    d = 16
+    qs16 = np.linspace(-6.0, 6.0, d)
+    arrays["qs16"] = qs16
+
+    def exact_mps(psi):
+        """Reference MPS holding ``psi`` exactly (successive SVDs, nothing truncated)."""
+        n_modes = psi.ndim
+        sites, rest, chi = [], psi.reshape(1, -1), 1
+        for _ in range(n_modes - 1):
+            u, s, vh = np.linalg.svd(rest.reshape(chi * d, -1), full_matrices=False)
+            sites.append(u.reshape(chi, d, -1))
+            chi = u.shape[1]
+            rest = s[:, None] * vh
+        sites.append(rest.reshape(chi, d, 1))
+        mps = RefMPS(qs16, sites)
+        assert np.allclose(mps.contract(), psi)
+        return mps
+
+    for n_modes in (2, 3):
+        psi = rng.standard_normal((d,) * n_modes) + 1j * rng.standard_normal((d,) * n_modes)
+        psi /= np.sqrt(np.sum(np.abs(psi) ** 2) * ((qs16[-1] - qs16[0]) / (d - 1)) ** n_modes)
+        arrays[f"meas_in_{n_modes}"] = psi
+        for label, make in [("Mq", lambda i, r: ref_cv.Mq(i, r)), ("Mp", lambda i, r: ref_cv.Mp(i, r)),
+                            ("Hom0.7", lambda i, r: ref_cv.Homodyne(i, 0.7, r)),
+                            ("Hompi", lambda i, r: ref_cv.Homodyne(i, np.pi, r))]:
+            for index in range(n_modes):
+                for forced in (-1.3, 0.45):
+                    mps = exact_mps(psi)
+                    res = make(index, forced).apply(mps, rng=None)
+                    key = f"meas_{label}_{n_modes}_{index}_{forced}"
+                    arrays[key] = np.asarray(mps.contract(), dtype=np.complex128)
+                    cases.append({"kind": "measure", "key": key, "gate": label, "n_modes": n_modes, "index": index,
+                                  "forced": forced, "result": float(res.result), "probability": float(res.probability)})
+
+    # Insert chain + gates through the reference's Simulator (truncation off), vacuum / GKP inputs
+    gates = [ref_cv.Insert(0, RefCVState.VACUUM), ref_cv.Insert(1, RefCVState.GKP_PLUS, gkp_epsilon=0.3),
+             ref_cv.Insert(1, RefCVState.GKP_ZERO, gkp_epsilon=0.3), ref_cv.X(0, 0.4), ref_cv.CZ(0, 1, 0.5, **exact),
+             ref_cv.F(2), ref_cv.BS(1, 2, 0.6, **exact), ref_cv.P(1, 0.2), ref_cv.CX(1, 0, 0.5, **exact),
+             ref_cv.SWAP(0, 1, **exact), ref_cv.Homodyne(2, 0.4, 0.8), ref_cv.D(0, [0.3, -0.2]), ref_cv.Mp(0, -0.5)]
+    sim = RefCVSimulator(gates, rng_seed=3, svd_options={"rel_err": 0.0})
+    out = sim.run(RefMPS(qs16, []))
+    arrays["sim_out"] = np.asarray(out.contract(), dtype=np.complex128)
+    arrays["sim_results"] = np.array([[r.result, r.probability] for r in sim.results])
+    cases.append({"kind": "simulator", "key": "sim_out"})
+    save("cv_extra.npz", cases=json.dumps(cases), **arrays)
+
+
 if __name__ == "__main__":
     import logging
     logging.getLogger("simulators").setLevel(logging.ERROR)
+    if "--cv-extra-only" in sys.argv:
+        gen_cv_extra()
+        sys.exit(0)
     gen_single_gates()
     gen_expand_gate()
     gen_clifford()
