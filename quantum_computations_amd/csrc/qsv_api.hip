@@ -207,6 +207,7 @@ int qsv_destroy(qsv_state *st) {
     (void)hipSetDevice(st->device);
     if (st->stream || st->data) (void)hipStreamSynchronize(st->stream);
     if (st->owns_data && st->data) (void)hipFree(st->data);
+    if (st->spare) (void)hipFree(st->spare);
     if (st->partials) (void)hipFree(st->partials);
     if (st->partials_host) (void)hipHostFree(st->partials_host);
     if (st->dev_matrix) (void)hipFree(st->dev_matrix);

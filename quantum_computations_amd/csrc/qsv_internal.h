@@ -57,6 +57,8 @@ struct qsv_state {
     uint64_t capacity = 0;   // slots available at `data`
     amp_t *data = nullptr;
     bool owns_data = false;
+    amp_t *spare = nullptr;  // second buffer of the out-of-place operations (ping-pong with `data`)
+    uint64_t spare_capacity = 0;
     hipStream_t stream = nullptr;
     // workspace
     double *partials = nullptr;       // device: reduction partials (2 doubles per workgroup)
@@ -101,7 +103,8 @@ int qsvk_fill_random(qsv_state *st, uint64_t seed, uint64_t index_offset, double
 int qsvk_scale(qsv_state *st, double re, double im);
 int qsvk_set_basis(qsv_state *st, uint64_t index);
 int qsvk_ensure_matrix(qsv_state *st, size_t bytes);
-int qsvk_scratch(qsv_state *st, uint64_t amps, amp_t **out);  // temporary device buffer (caller frees)
+int qsvk_scratch(qsv_state *st, uint64_t amps, amp_t **out);  // the state's persistent spare buffer (never freed by callers)
+int qsvk_adopt(qsv_state *st, uint64_t new_amps);              // make the spare buffer the register
 
 int qsvq_mode1(qsv_state *st, int mode, const double *m, bool diag);
 int qsvq_mode2(qsv_state *st, int mode0, int mode1, const double *m, bool diag);

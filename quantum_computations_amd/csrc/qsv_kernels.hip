@@ -604,10 +604,37 @@ int qsvk_ensure_matrix(qsv_state *st, size_t bytes) {
     return QSV_OK;
 }
 
+// Out-of-place operations (measure, insert, permute, the mode contractions) write into the state's spare
+// buffer and then swap it in (qsvk_adopt).  The spare is kept between calls: a circuit that alternates such
+// operations ping-pongs between two allocations instead of paying hipMalloc/hipFree of the register per gate
+// (measured: ~0.44 s per gate on a 16 GiB register).
 int qsvk_scratch(qsv_state *st, uint64_t amps, amp_t **out) {
-    (void)st;
-    if (hipMalloc(reinterpret_cast<void **>(out), sizeof(amp_t) * (amps ? amps : 1)) != hipSuccess)
-        return qsv_fail(QSV_ENOMEM, "device allocation of a scratch register failed");
+    if (amps == 0) amps = 1;
+    if (st->spare_capacity < amps) {
+        if (st->spare) {
+            QSV_HIP(hipStreamSynchronize(st->stream));
+            QSV_HIP(hipFree(st->spare));
+            st->spare = nullptr;
+            st->spare_capacity = 0;
+        }
+        if (hipMalloc(reinterpret_cast<void **>(&st->spare), sizeof(amp_t) * amps) != hipSuccess)
+            return qsv_fail(QSV_ENOMEM, "device allocation of the spare register failed");
+        st->spare_capacity = amps;
+    }
+    *out = st->spare;
+    return QSV_OK;
+}
+
+// The spare buffer now holds the register (new_amps amplitudes): swap it in when the library owns the memory,
+// copy it back when the caller does (a view's pointer must stay valid).
+int qsvk_adopt(qsv_state *st, uint64_t new_amps) {
+    if (st->owns_data) {
+        std::swap(st->data, st->spare);
+        std::swap(st->capacity, st->spare_capacity);
+    } else {
+        QSV_HIP(hipMemcpyAsync(st->data, st->spare, sizeof(amp_t) * new_amps, hipMemcpyDeviceToDevice, st->stream));
+    }
+    st->amps = new_amps;
     return QSV_OK;
 }
 
@@ -784,21 +811,9 @@ int qsvk_measure_probs(qsv_state *st, int bit, const double e0[4], const double 
     return sum_partials(st, grid, p0, p1);
 }
 
-// Replace the register by `fresh` (holding new_amps amplitudes): adopt it when the library owns the
-// memory, copy back when the caller does (the view pointer must stay valid).
 static int adopt(qsv_state *st, amp_t *fresh, uint64_t new_amps) {
-    if (st->owns_data) {
-        QSV_HIP(hipStreamSynchronize(st->stream));
-        QSV_HIP(hipFree(st->data));
-        st->data = fresh;
-        st->capacity = new_amps;
-    } else {
-        QSV_HIP(hipMemcpyAsync(st->data, fresh, sizeof(amp_t) * new_amps, hipMemcpyDeviceToDevice, st->stream));
-        QSV_HIP(hipStreamSynchronize(st->stream));
-        QSV_HIP(hipFree(fresh));
-    }
-    st->amps = new_amps;
-    return QSV_OK;
+    (void)fresh;  // == st->spare
+    return qsvk_adopt(st, new_amps);
 }
 
 int qsvk_collapse(qsv_state *st, int bit, const double e[4], double scale) {
@@ -810,10 +825,7 @@ int qsvk_collapse(qsv_state *st, int bit, const double e[4], double scale) {
     hipLaunchKernelGGL(k_collapse, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, pairs, bit,
                        cplx{e[0], e[1]}, cplx{e[2], e[3]}, scale);
     rc = check_launch();
-    if (rc) {
-        (void)hipFree(fresh);
-        return rc;
-    }
+    if (rc) return rc;
     st->n -= 1;
     return adopt(st, fresh, pairs);
 }
@@ -829,10 +841,7 @@ int qsvk_insert(qsv_state *st, int bit, const double amp[4]) {
     hipLaunchKernelGGL(k_insert, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, out_amps, bit,
                        cplx{amp[0], amp[1]}, cplx{amp[2], amp[3]});
     rc = check_launch();
-    if (rc) {
-        (void)hipFree(fresh);
-        return rc;
-    }
+    if (rc) return rc;
     st->n += 1;
     return adopt(st, fresh, out_amps);
 }
@@ -848,10 +857,7 @@ int qsvk_permute(qsv_state *st, const int *src_bit_of_dst_bit) {
     const int grid = grid_for(st->amps, QSV_BLOCK * 4, 8192);
     hipLaunchKernelGGL(k_permute, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, st->amps, g);
     rc = check_launch();
-    if (rc) {
-        (void)hipFree(fresh);
-        return rc;
-    }
+    if (rc) return rc;
     return adopt(st, fresh, st->amps);
 }
 

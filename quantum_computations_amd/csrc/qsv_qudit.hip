@@ -247,18 +247,10 @@ int launch_axis(hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uin
     return check_launch();
 }
 
-// Replace the register by `fresh` (see qsv_kernels.hip::adopt).
+// The spare buffer (`fresh`) now holds the register: swap it in (qsv_kernels.hip::qsvk_adopt).
 int adopt(qsv_state *st, amp_t *fresh) {
-    if (st->owns_data) {
-        QSV_HIP(hipStreamSynchronize(st->stream));
-        QSV_HIP(hipFree(st->data));
-        st->data = fresh;
-    } else {
-        QSV_HIP(hipMemcpyAsync(st->data, fresh, sizeof(amp_t) * st->amps, hipMemcpyDeviceToDevice, st->stream));
-        QSV_HIP(hipStreamSynchronize(st->stream));
-        QSV_HIP(hipFree(fresh));
-    }
-    return QSV_OK;
+    (void)fresh;
+    return qsvk_adopt(st, st->amps);
 }
 
 }  // namespace
@@ -282,10 +274,7 @@ int qsvq_mode1(qsv_state *st, int mode, const double *m, bool diag) {
     rc = qsvk_scratch(st, st->amps, &fresh);
     if (rc) return rc;
     rc = launch_axis(st->stream, st->data, fresh, L, d, d, R, st->dev_matrix);
-    if (rc) {
-        (void)hipFree(fresh);
-        return rc;
-    }
+    if (rc) return rc;
     return adopt(st, fresh);
 }
 
@@ -336,10 +325,7 @@ int qsvq_mode2(qsv_state *st, int mode0, int mode1, const double *m, bool diag) 
     hipLaunchKernelGGL(k_mode2_simple, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, L,
                        static_cast<int>(d), Mid, R, st->dev_matrix);
     rc = check_launch();
-    if (rc) {
-        (void)hipFree(fresh);
-        return rc;
-    }
+    if (rc) return rc;
     return adopt(st, fresh);
 }
 
@@ -376,10 +362,7 @@ int qsvq_mode2_gather(qsv_state *st, int mode0, int mode1, int nnz, const int32_
     hipLaunchKernelGGL(k_mode2_gather, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, L,
                        static_cast<int>(d), Mid, R, nnz, dcols, st->dev_matrix);
     rc = check_launch();
-    if (rc) {
-        (void)hipFree(fresh);
-        return rc;
-    }
+    if (rc) return rc;
     return adopt(st, fresh);
 }
 
@@ -407,18 +390,8 @@ int qsvq_mode_marginal(qsv_state *st, int mode, double *probs) {
 
 // Replace the register by `fresh` holding new_amps amplitudes (the mode count changed).
 static int adopt_resized(qsv_state *st, amp_t *fresh, uint64_t new_amps) {
-    if (st->owns_data) {
-        QSV_HIP(hipStreamSynchronize(st->stream));
-        QSV_HIP(hipFree(st->data));
-        st->data = fresh;
-        st->capacity = new_amps;
-    } else {
-        QSV_HIP(hipMemcpyAsync(st->data, fresh, sizeof(amp_t) * new_amps, hipMemcpyDeviceToDevice, st->stream));
-        QSV_HIP(hipStreamSynchronize(st->stream));
-        QSV_HIP(hipFree(fresh));
-    }
-    st->amps = new_amps;
-    return QSV_OK;
+    (void)fresh;
+    return qsvk_adopt(st, new_amps);
 }
 
 int qsvq_mode_project(qsv_state *st, int mode, int level, double scale) {
@@ -430,10 +403,7 @@ int qsvq_mode_project(qsv_state *st, int mode, int level, double scale) {
     hipLaunchKernelGGL(k_mode_project, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, L,
                        static_cast<int>(d), R, level, scale);
     rc = check_launch();
-    if (rc) {
-        (void)hipFree(fresh);
-        return rc;
-    }
+    if (rc) return rc;
     st->n -= 1;
     return adopt_resized(st, fresh, L * R);
 }
@@ -453,10 +423,7 @@ int qsvq_mode_insert(qsv_state *st, int mode, const double *vec) {
     hipLaunchKernelGGL(k_mode_insert, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, L,
                        static_cast<int>(d), R, st->dev_matrix);
     rc = check_launch();
-    if (rc) {
-        (void)hipFree(fresh);
-        return rc;
-    }
+    if (rc) return rc;
     QSV_HIP(hipStreamSynchronize(st->stream));  // `vec` was read by the async copy
     st->n += 1;
     return adopt_resized(st, fresh, out_amps);

@@ -114,6 +114,40 @@ def random_ket(n: int, seed: int, chunk_bits: int = 24) -> np.ndarray:
     return out
 
 
+# ---- n-qubit Grover (cfg5).  Build-defined generalisation: the reference only has the 3-qubit circuit below ----
+def grover_iteration(state, n: int, marked: int) -> None:
+    """One Grover iteration on a device register (``DeviceState`` / ``ShardedState``): phase oracle on the basis
+    state ``marked`` (X on its zero bits, multi-controlled Z, X back) followed by the diffuser H X (MCZ) X H.
+    Same structure as ``dv_circuits.grover`` (``impact_.../dv_circuits.py:50-79``) with its hand-decomposed CCZ
+    replaced by one multi-controlled phase on all n qubits (``qsv_apply_mcphase``)."""
+    h, x = G.H(0).matrix, G.X(0).matrix
+    zeros = [q for q in range(n) if not (marked >> (n - 1 - q)) & 1]
+    for q in zeros:
+        state.apply_matrix(x, [q])
+    state.apply_mcphase(list(range(n)), -1.0)
+    for q in zeros:
+        state.apply_matrix(x, [q])
+    for q in range(n):
+        state.apply_matrix(h, [q])
+    for q in range(n):
+        state.apply_matrix(x, [q])
+    state.apply_mcphase(list(range(n)), -1.0)
+    for q in range(n):
+        state.apply_matrix(x, [q])
+    for q in range(n):
+        state.apply_matrix(h, [q])
+
+
+def grover_gate_count(n: int, marked: int) -> int:
+    zeros = sum(1 for q in range(n) if not (marked >> (n - 1 - q)) & 1)
+    return 2 * zeros + 4 * n + 2
+
+
+def grover_success_probability(n: int, iterations: int, n_marked: int = 1) -> float:
+    """sin^2((2k + 1) asin(sqrt(M / 2^n))): the analytic success probability after k iterations."""
+    return float(np.sin((2 * iterations + 1) * np.arcsin(np.sqrt(n_marked / 2.0 ** n))) ** 2)
+
+
 # ---- Grover (cfg5): the reference pins the 3-qubit instance (impact_.../dv_circuits.py:27-109) -------------
 def ccz_ops() -> list[dict]:
     """The reference's 15-gate nearest-neighbour CCZ on qubits (0, 1, 2) (``dv_circuits.py:27-48``)."""
