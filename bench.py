@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fusion", action="store_true", help="skip the informational fused-circuit measurement")
     ap.add_argument("--qubits-per-gpu", type=int, default=QUBITS_PER_GPU)
     args = ap.parse_args()
 
@@ -216,6 +217,25 @@ def main():
     if cpu is not None:
         result["cpu_baseline"] = cpu
         result["parity_max_abs_err_vs_cpu_at_full_size"] = parity_err
+    if world == 1 and not args.no_fusion:
+        # Informational, outside the timed region and NOT part of `value`: the same circuit through the gate-fusion
+        # scheduler of Simulator(fuse=k) (quantum_computations_amd/fusion.py) -- fewer, denser launches.
+        from quantum_computations_amd.fusion import fuse_circuit, fusion_stats
+        result["with_gate_fusion"] = {}
+        for k in (3, 4, 5):
+            fused = fuse_circuit(gates, k)
+            for g in fused:
+                g.apply(dev)
+            dev.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                for g in fused:
+                    g.apply(dev)
+            dev.sync()
+            dt = time.perf_counter() - t0
+            result["with_gate_fusion"][f"max_{k}_qubits"] = {
+                **fusion_stats(gates, fused), "gate_apps_per_sec": args.steps * DEPTH / dt,
+                "ms_per_step": 1e3 * dt / args.steps}
     print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -266,6 +266,83 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_generic(amp_t *__restrict__ a, co
 }
 
 // ----------------------------------------------------------------------------------------------------
+// Register-blocked k-qubit dense gate (k = 3..5: fused gate blocks, Gate(indices, matrix) with many legs).
+// A thread owns the 2^k amplitudes of one group in registers (k = 5: 128 VGPRs), the six lowest NON-target bits
+// are the lane bits, rows are produced one at a time with the matrix read through scalar loads (wave-uniform
+// addresses -> s_load_dwordx16, no LDS) and stored in place.  2^k complex FMAs per amplitude: k = 5 is
+// 8 flop/B, close to the fp64 ridge of the chip, so this kernel is bounded by HBM *and* the fp64 pipe.
+// Device table layout behind M: [2^k x 2^k complex matrix][2^k uint64 amplitude offsets].
+// ----------------------------------------------------------------------------------------------------
+//
+// Target bits below 6 (KL of them) are lane bits, and a wave must keep touching 64 consecutive amplitudes per
+// instruction.  So the thread loads 2^k coalesced amplitudes over the KH high targets and KL *stand-in* high
+// bits E_j instead, and the wave then swaps the roles of lane bit L_j and register bit e_j with KL butterfly
+// stages of wave64 shuffles (a distributed transpose): afterwards every thread holds one complete group.  The
+// same stages, applied to the outputs, restore the memory layout before the coalesced stores.
+struct BigArgs {
+    uint64_t W;
+    int32_t nins;
+    uint8_t pos[2 * QSV_MAX_K];  // ascending: high targets and stand-in bits
+    uint64_t or_mask;            // unused (0); lets deposit() serve this struct too
+    int32_t lbit[QSV_MAX_K];     // lane-bit position of low target j (register index bit j)
+};
+
+template <int D, int KL>
+__device__ __forceinline__ void wave_transpose(amp_t (&x)[D], const BigArgs &g, int lane) {
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+        const int lb = g.lbit[j];
+        const bool up = (lane >> lb) & 1;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            if (c & (1 << j)) continue;
+            const amp_t r0 = x[c], r1 = x[c | (1 << j)];
+            const amp_t recv = shfl_xor_amp(up ? r0 : r1, 1 << lb);  // I keep entry e_j == my bit, trade the other
+            x[c] = up ? recv : r0;
+            x[c | (1 << j)] = up ? r1 : recv;
+        }
+    }
+}
+
+template <int K, int KL, bool NT>
+__global__ __launch_bounds__(QSV_BLOCK) void k_dense_big(amp_t *__restrict__ a, const BigArgs g,
+                                                        const double *__restrict__ M,
+                                                        const uint64_t *__restrict__ hoff) {
+    constexpr int D = 1 << K;
+    const uint64_t w = blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x;
+    if (w >= g.W) return;  // W is a multiple of 64 whenever KL > 0: whole waves leave together
+    const uint64_t base = deposit(w, g);
+    amp_t x[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[c] = ld<NT>(a + base + hoff[c]);
+    if constexpr (KL == 0) {
+#pragma unroll 1
+        for (int r = 0; r < D; ++r) {
+            const double *row = M + 2 * D * r;
+            amp_t acc = {0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc = cfma(cplx{row[2 * c], row[2 * c + 1]}, x[c], acc);
+            st<NT>(a + base + hoff[r], acc);  // in place: every input of this group is already in registers
+        }
+    } else {
+        const int lane = threadIdx.x & 63;
+        wave_transpose<D, KL>(x, g, lane);
+        amp_t y[D];
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            const double *row = M + 2 * D * r;
+            amp_t acc = {0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc = cfma(cplx{row[2 * c], row[2 * c + 1]}, x[c], acc);
+            y[r] = acc;
+        }
+        wave_transpose<D, KL>(y, g, lane);
+#pragma unroll
+        for (int c = 0; c < D; ++c) st<NT>(a + base + hoff[c], y[c]);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
 // Reductions, measurement, insertion, permutation, fills.
 // ----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
@@ -638,8 +715,108 @@ int qsvk_adopt(qsv_state *st, uint64_t new_amps) {
     return QSV_OK;
 }
 
+// k = 3..5 on any register with at least k qubits.
+template <int K, int KL>
+static void launch_big_kernel(qsv_state *st, bool nt, dim3 gd, const BigArgs &g, const uint64_t *dev_off) {
+    const dim3 bd(QSV_BLOCK);
+    if (nt) hipLaunchKernelGGL((k_dense_big<K, KL, true>), gd, bd, 0, st->stream, st->data, g, st->dev_matrix, dev_off);
+    else hipLaunchKernelGGL((k_dense_big<K, KL, false>), gd, bd, 0, st->stream, st->data, g, st->dev_matrix, dev_off);
+}
+
+template <int K>
+static int dispatch_big(qsv_state *st, int KL, bool nt, dim3 gd, const BigArgs &g, const uint64_t *dev_off) {
+    switch (KL) {
+        case 0: launch_big_kernel<K, 0>(st, nt, gd, g, dev_off); break;
+        case 1: launch_big_kernel<K, 1>(st, nt, gd, g, dev_off); break;
+        case 2: launch_big_kernel<K, 2>(st, nt, gd, g, dev_off); break;
+        case 3: launch_big_kernel<K, 3>(st, nt, gd, g, dev_off); break;
+        case 4:
+            if constexpr (K >= 4) launch_big_kernel<K, 4>(st, nt, gd, g, dev_off);
+            break;
+        default:
+            if constexpr (K >= 5) launch_big_kernel<K, 5>(st, nt, gd, g, dev_off);
+            break;
+    }
+    return check_launch();
+}
+
+// k = 3..5 on any register with at least k qubits.  bits[j] = bit position of matrix leg j (leg 0 most significant).
+static int launch_dense_big(qsv_state *st, int k, const int *bits, const double *m_user) {
+    const int D = 1 << k;
+    std::vector<int> high, low;
+    for (int j = 0; j < k; ++j) (bits[j] >= QSV_LANE_BITS ? high : low).push_back(bits[j]);
+    int KL = static_cast<int>(low.size());
+    // stand-in bits for the low targets: the lowest free bits >= 6 (needs n >= k + 6)
+    std::vector<int> standin;
+    for (int b = QSV_LANE_BITS; b < st->n && static_cast<int>(standin.size()) < KL; ++b)
+        if (std::find(high.begin(), high.end(), b) == high.end()) standin.push_back(b);
+    const bool transposed = KL > 0 && static_cast<int>(standin.size()) == KL;
+    if (!transposed) {  // all targets high, or a register too small to transpose: lanes = lowest free bits
+        high.assign(bits, bits + k);
+        low.clear();
+        standin.clear();
+        KL = 0;
+    }
+    const int KH = k - KL;
+    // register index c = (h << KL) | t: h bit i <-> high[i], t bit j <-> low[j] (stored at stand-in bit standin[j])
+    BigArgs g;
+    std::memset(&g, 0, sizeof(g));
+    std::vector<uint64_t> off(D, 0);
+    for (int c = 0; c < D; ++c) {
+        for (int i = 0; i < KH; ++i)
+            if ((c >> (KL + i)) & 1) off[c] |= 1ull << high[i];
+        for (int j = 0; j < KL; ++j)
+            if ((c >> j) & 1) off[c] |= 1ull << standin[j];
+    }
+    for (int j = 0; j < KL; ++j) g.lbit[j] = low[j];
+    auto user_index = [&](int c) {  // kernel register index -> index of the caller's matrix
+        int u = 0;
+        for (int leg = 0; leg < k; ++leg) {
+            int v = 0;
+            for (int i = 0; i < KH; ++i)
+                if (high[i] == bits[leg]) v = (c >> (KL + i)) & 1;
+            for (int j = 0; j < KL; ++j)
+                if (low[j] == bits[leg]) v = (c >> j) & 1;
+            u |= v << (k - 1 - leg);
+        }
+        return u;
+    };
+    std::vector<double> m(2ull * D * D);
+    for (int r = 0; r < D; ++r)
+        for (int c = 0; c < D; ++c) {
+            const int ur = user_index(r), uc = user_index(c);
+            m[2 * (r * D + c)] = m_user[2 * (ur * D + uc)];
+            m[2 * (r * D + c) + 1] = m_user[2 * (ur * D + uc) + 1];
+        }
+    const size_t mbytes = sizeof(double) * m.size(), obytes = sizeof(uint64_t) * D;
+    int rc = qsvk_ensure_matrix(st, mbytes + obytes);
+    if (rc) return rc;
+    uint64_t *dev_off = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(st->dev_matrix) + mbytes);
+    QSV_HIP(hipMemcpyAsync(st->dev_matrix, m.data(), mbytes, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipMemcpyAsync(dev_off, off.data(), obytes, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));  // both sources are pageable host memory that dies at return
+    g.W = st->amps >> k;
+    std::vector<int> ins(high);
+    ins.insert(ins.end(), standin.begin(), standin.end());
+    std::sort(ins.begin(), ins.end());
+    g.nins = static_cast<int>(ins.size());
+    for (size_t j = 0; j < ins.size(); ++j) g.pos[j] = static_cast<uint8_t>(ins[j]);
+    const dim3 gd(grid_for(g.W, QSV_BLOCK, 0));
+    // partial-line nontemporal accesses are slow: use them only when every access is a full 1 KiB per wave
+    bool coalesced = true;
+    for (int b : ins) coalesced = coalesced && b >= QSV_LANE_BITS;
+    const bool nt = st->nontemporal != 0 && coalesced;
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_big<%d, %d, %s>", k, KL, nt ? "true" : "false");
+    switch (k) {
+        case 3: return dispatch_big<3>(st, KL, nt, gd, g, dev_off);
+        case 4: return dispatch_big<4>(st, KL, nt, gd, g, dev_off);
+        default: return dispatch_big<5>(st, KL, nt, gd, g, dev_off);
+    }
+}
+
 int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user) {
     if (k < 1 || k > QSV_MAX_K) return qsv_fail(QSV_EINVAL, "generic gate: k must be in 1..6");
+    if (k >= 3 && k <= 5 && st->n >= k) return launch_dense_big(st, k, bits, m_user);
     const size_t bytes = sizeof(double) * 2ull << (2 * k);
     int rc = qsvk_ensure_matrix(st, bytes);
     if (rc) return rc;

@@ -1,0 +1,101 @@
+"""Gate fusion for ``Simulator.run``: merge neighbouring gates into dense blocks of at most ``max_qubits`` qubits.
+
+The gate path is bandwidth-bound -- one pass over the register per kernel, and a dense k-qubit block (k <= 4..5) costs
+about the same pass as a single 1-qubit gate (``k_dense_big``: 5.2-5.9 TB/s for k = 3..4 on an MI355X) -- so applying
+m gates as one block divides their cost by m.  This sits exactly where the reference loops over the circuit
+(``simulators/dv_simulator/simulator.py:40-52``); SURVEY.md 8f ranks it first among the "next" rows.
+
+Scheduler: a list of open blocks with pairwise disjoint qubit sets.  A new gate joins the blocks it touches if the
+union stays within ``max_qubits`` (the touched blocks are merged), otherwise those blocks are flushed to the output
+and the gate opens a new block.  Disjoint blocks commute, so the order in which they are flushed is free; gates that
+share a qubit always keep their order.  Measurements, insertions and classically controlled gates are barriers (they
+change the register size or depend on run-time results): everything is flushed before them.  A block that ends up
+holding a single gate is emitted as that gate, so the reduced-traffic kernels (CZ, CX, SWAP, diagonals) still apply.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .dv_simulator.gates import Gate, Insert, M
+
+
+def _apply_to_rows(block: np.ndarray, k: int, matrix: np.ndarray, legs: list[int]) -> np.ndarray:
+    """``G_embedded @ block`` where ``matrix`` acts on the row legs ``legs`` of the 2^k x 2^k ``block``."""
+    g = np.asarray(matrix, dtype=np.complex128).reshape((2,) * (2 * len(legs)))
+    t = block.reshape((2,) * k + (-1,))
+    t = np.tensordot(g, t, axes=(list(range(len(legs), 2 * len(legs))), legs))
+    t = np.moveaxis(t, list(range(len(legs))), legs)
+    return np.ascontiguousarray(t).reshape(1 << k, 1 << k)
+
+
+class _Block:
+    def __init__(self, gate: Gate):
+        self.qubits: list[int] = list(gate.indices)
+        self.matrix = np.asarray(gate.matrix, dtype=np.complex128)
+        self.gates = [gate]
+
+    def absorb(self, gate: Gate) -> None:
+        self.matrix = _apply_to_rows(self.matrix, len(self.qubits), gate.matrix,
+                                     [self.qubits.index(q) for q in gate.indices])
+        self.gates.append(gate)
+
+    def grow(self, qubits: list[int]) -> None:
+        """Extend to more qubits (identity on the new ones, appended as less significant legs)."""
+        extra = [q for q in qubits if q not in self.qubits]
+        if extra:
+            self.matrix = np.kron(self.matrix, np.identity(1 << len(extra)))
+            self.qubits += extra
+
+    def merge(self, other: "_Block") -> None:
+        """Tensor product with a block on disjoint qubits."""
+        self.matrix = np.kron(self.matrix, other.matrix)
+        self.qubits += other.qubits
+        self.gates += other.gates
+
+    def emit(self):
+        if len(self.gates) == 1:
+            return self.gates[0]
+        fused = Gate(list(self.qubits), self.matrix)
+        fused.sources = list(self.gates)      # the gates this block replaces (Simulator uses them for dtype parity)
+        return fused
+
+
+def fuse_circuit(circuit: list, max_qubits: int = 4) -> list:
+    """Return an equivalent circuit in which runs of plain gates are merged into blocks of <= ``max_qubits`` qubits."""
+    if max_qubits < 2:
+        return list(circuit)
+    out: list = []
+    open_blocks: list[_Block] = []
+
+    def flush(blocks):
+        for b in blocks:
+            out.append(b.emit())
+            open_blocks.remove(b)
+
+    for gate in circuit:
+        plain = isinstance(gate, Gate) and not isinstance(gate, (M, Insert)) and gate.matrix is not None \
+            and gate.matrix.shape[0] == gate.matrix.shape[1]
+        if not plain or len(gate.indices) > max_qubits:
+            flush(list(open_blocks))
+            out.append(gate)
+            continue
+        touched = [b for b in open_blocks if set(b.qubits) & set(gate.indices)]
+        union = set(gate.indices).union(*(b.qubits for b in touched))
+        if touched and len(union) <= max_qubits:
+            first = touched[0]
+            for other in touched[1:]:
+                first.merge(other)
+                open_blocks.remove(other)
+            first.grow(list(gate.indices))
+            first.absorb(gate)
+        else:
+            flush(touched)
+            open_blocks.append(_Block(gate))
+    flush(list(open_blocks))
+    return out
+
+
+def fusion_stats(circuit: list, fused: list) -> dict:
+    sizes = [len(g.indices) for g in fused if isinstance(g, Gate)]
+    return {"gates": len(circuit), "launches": len(fused), "gates_per_launch": len(circuit) / max(1, len(fused)),
+            "block_sizes": {k: sizes.count(k) for k in sorted(set(sizes))}}

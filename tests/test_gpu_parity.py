@@ -246,6 +246,30 @@ def test_generic_kq(n, k):
     assert maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL
 
 
+@pytest.mark.parametrize("k", [3, 4, 5])
+def test_register_blocked_kq_every_low_target_count(k):
+    """k_dense_big: 0..k of the targets among the six lane bits (the wave-transpose stages), legs in any order."""
+    n = k + 8
+    rng = np.random.default_rng(50 + k)
+    ket = W.random_ket(n, 31)
+    dev = DeviceState.from_numpy(ket)
+    want = ket
+    kernels = set()
+    for n_low in range(k + 1):
+        for trial in range(2):
+            low_bits = [int(b) for b in rng.choice(6, size=n_low, replace=False)]
+            high_bits = [int(b) for b in rng.choice(np.arange(6, n), size=k - n_low, replace=False)]
+            bits = low_bits + high_bits
+            rng.shuffle(bits)
+            qs = [n - 1 - b for b in bits]
+            u = W.haar_unitary(1 << k, rng)
+            dev.apply_matrix(u, qs)
+            kernels.add(dev.last_kernel())
+            want = O.apply_gate(want, u, qs)
+            assert maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL, (bits, dev.last_kernel())
+    assert len(kernels) == k + 1, kernels          # every KL instantiation was exercised
+
+
 @pytest.mark.parametrize("n", [1, 4, 9, 12])
 def test_measure_insert_every_position(n):
     ket = W.random_ket(n, 21)

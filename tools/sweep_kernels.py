@@ -106,6 +106,20 @@ def main():
         dev.set_option(_lib.OPT_UNROLL, 0)
         dev.set_option(_lib.OPT_NONTEMPORAL, 1)
 
+    emit("\n## register-blocked k-qubit dense gates (k = 3..5): GB/s by target-bit set")
+    for k in (3, 4, 5):
+        uk = W.haar_unitary(1 << k, rng)
+        sets = {"high": [8 + 3 * j for j in range(k)], "top": [n - 1 - j for j in range(k)],
+                "mixed": [0, 3][: max(1, k - 3)] + [7 + 4 * j for j in range(k - max(1, k - 3))],
+                "low": list(range(k)), "far": [20 + j for j in range(k)]}
+        for label, bits in sets.items():
+            for nt in (1, 0):
+                dev.set_option(_lib.OPT_NONTEMPORAL, nt)
+                ms = timed(dev, lambda: dev.apply_matrix(uk, [n - 1 - b for b in bits]), max(3, args.reps // 2))
+                emit(f"k={k} {label:6s} bits={str(bits):22s} nt={nt}  {ms:7.3f} ms  {gbytes / (ms * 1e-3):7.0f} GB/s"
+                     f"  {dev.last_kernel()}")
+    dev.set_option(_lib.OPT_NONTEMPORAL, 1)
+
     emit("\n## specialised kernels (credited with the full algorithmic bytes): ms and equivalent GB/s")
     d1 = np.exp(1j * rng.uniform(0, 6.28, 2))
     d2 = np.exp(1j * rng.uniform(0, 6.28, 4))
