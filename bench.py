@@ -128,6 +128,8 @@ def main():
 
     def step(record: bool, slot0: int = 0):
         slot = slot0
+        if world > 1:
+            dev.prepare(gates)       # what Simulator.run does: lets the shards plan which qubit to give up
         for gate in gates:
             if record:
                 dev.event_record(slot)

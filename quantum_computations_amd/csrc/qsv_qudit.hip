@@ -257,6 +257,20 @@ int adopt(qsv_state *st, amp_t *fresh) {
 
 int qsvq_mode1(qsv_state *st, int mode, const double *m, bool diag) {
     const uint64_t d = st->d, R = ipow(d, st->n - 1 - mode), L = ipow(d, mode);
+    // d = 2^K levels: the register IS a (K * n_modes)-qubit register and the mode gate a K-qubit gate on K
+    // consecutive bits -- use the in-place, register-blocked qubit kernels (k_dense / k_dense_big) instead of the
+    // out-of-place contraction below.
+    int K = 0;
+    while ((1ull << K) < d) ++K;
+    if (!diag && (1ull << K) == d && K >= 1 && K <= 5) {
+        int bits[5];
+        for (int j = 0; j < K; ++j) bits[j] = K * (st->n - 1 - mode) + (K - 1 - j);  // leg 0 = top bit of the level
+        const int modes = st->n;
+        st->n = K * modes;  // the qubit kernels read the register size from the state
+        const int rc = K <= 2 ? qsvk_dense(st, K, bits, 0, nullptr, m) : qsvk_generic(st, K, bits, m);
+        st->n = modes;
+        return rc;
+    }
     const size_t bytes = sizeof(double) * 2 * (diag ? d : d * d);
     int rc = qsvk_ensure_matrix(st, bytes);
     if (rc) return rc;

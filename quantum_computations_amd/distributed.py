@@ -77,6 +77,8 @@ class ShardedState:
         self.phys = list(range(n_qubits))
         self.exchanges = 0                                # half-shard exchanges performed (for reports)
         self.bytes_sent = 0
+        self._plan = None                                 # look-ahead set by prepare(): [(indices, mixing qubits)]
+        self._cursor = 0
 
     # ---- construction ---------------------------------------------------------------------------
     @classmethod
@@ -151,10 +153,14 @@ class ShardedState:
     # host memory (gloo on a box with fewer GPUs than ranks); production uses them as written, on RCCL.
     def _exchange(self, send, recv, peer: int) -> None:
         """Simultaneous send of ``send`` to ``peer`` and receive of ``recv`` from it (grouped ncclSend/ncclRecv)."""
+        import torch
+
         dist = self._dist
         peer_global = dist.get_global_rank(self.group, peer) if self.group is not None else peer
-        ops = [dist.P2POp(dist.isend, send, peer_global, self.group),
-               dist.P2POp(dist.irecv, recv, peer_global, self.group)]
+        # RCCL has no complex dtype: move the amplitudes as (re, im) float64 pairs (same bytes, no copy)
+        send_r, recv_r = torch.view_as_real(send), torch.view_as_real(recv)
+        ops = [dist.P2POp(dist.isend, send_r, peer_global, self.group),
+               dist.P2POp(dist.irecv, recv_r, peer_global, self.group)]
         for work in dist.batch_isend_irecv(ops):
             work.wait()
 
@@ -168,9 +174,55 @@ class ShardedState:
     def _allgather_shards(self):
         import torch
 
-        shards = [torch.empty_like(self.buf) for _ in range(self.world)]
-        self._dist.all_gather(shards, self.buf.contiguous(), group=self.group)
-        return torch.cat(shards).cpu().numpy()
+        mine = torch.view_as_real(self.buf.contiguous())
+        shards = [torch.empty_like(mine) for _ in range(self.world)]
+        self._dist.all_gather(shards, mine, group=self.group)
+        return torch.view_as_complex(torch.cat(shards)).cpu().numpy()
+
+    # ---- look-ahead: which local qubit to give up ---------------------------------------------------
+    def prepare(self, circuit) -> None:
+        """Tell the register which gates are about to be applied (objects with ``indices`` / ``matrix``, in order).
+
+        With the plan, an exchange evicts the local qubit whose next *mixing* use lies farthest ahead (Belady's
+        rule) instead of whichever qubit sits on the top local bit, which cuts the number of half-shard exchanges
+        of a random circuit several-fold.  Purely an optimisation: every rank computes the same plan from the same
+        circuit, a gate that does not match the plan simply switches the look-ahead off, and the plan stops at the
+        first measurement / insertion (they renumber the qubits)."""
+        plan = []
+        for gate in circuit:
+            inner = getattr(gate, "gate", gate)                     # ClassicalControl wraps a gate
+            matrix, indices = getattr(inner, "matrix", None), list(getattr(inner, "indices", []))
+            if matrix is None or np.asarray(matrix).shape[0] != np.asarray(matrix).shape[1]:
+                break
+            m = np.asarray(matrix, dtype=np.complex128)
+            k = len(indices)
+            mixing = frozenset(q for j, q in enumerate(indices) if not _leg_is_block_diagonal(m, k, j))
+            plan.append((tuple(indices), mixing))
+        self._plan, self._cursor = plan, 0
+
+    def _advance_plan(self, indices) -> None:
+        if self._plan is None:
+            return
+        if self._cursor >= len(self._plan) or self._plan[self._cursor][0] != tuple(indices):
+            self._plan = None                                        # the caller left the announced circuit
+            return
+        self._cursor += 1
+
+    def _next_mixing_use(self, qubit: int) -> int:
+        for step in range(self._cursor, len(self._plan)):
+            if qubit in self._plan[step][1]:
+                return step
+        return 1 << 60
+
+    def _choose_victim(self, avoid: set[int]) -> int:
+        top = self.n_local - 1
+        free = [b for b in range(self.n_local) if b not in avoid]
+        if not free:
+            raise ValueError("gate has more legs than a shard has qubits")
+        if self._plan is None:
+            return top if top in free else max(free)
+        # farthest next use first; among equals the highest bit (the top bit needs no local swap)
+        return max(free, key=lambda b: (self._next_mixing_use(self.n - 1 - self.phys.index(b)), b))
 
     def _localise(self, gbit: int, avoid: set[int]) -> int:
         """Swap global physical bit ``gbit`` with the top local bit (kept clear of ``avoid``); returns the
@@ -178,9 +230,9 @@ class ShardedState:
         import torch
 
         top = self.n_local - 1
-        if top in avoid:                        # the top local bit is a leg of this gate: park it lower first
-            free = max(b for b in range(self.n_local) if b not in avoid)
-            self._swap_bits_local(top, free)
+        victim = self._choose_victim(avoid)     # local bit whose qubit leaves the shard
+        if victim != top:                       # halves are contiguous only for the top bit: bring the victim there
+            self._swap_bits_local(top, victim)  # (one local pass; an exchange costs ~30x more)
         half = 1 << top
         mine = self._rank_bit(gbit)
         peer = self.rank ^ (1 << (gbit - self.n_local))
@@ -224,6 +276,7 @@ class ShardedState:
             raise ValueError("Indices must be distinct.")
         for q in qubits:
             self._bit(q)
+        self._advance_plan(qubits)
         conserved = [_leg_is_block_diagonal(m, k, j) for j in range(k)]
         mixing = [q for q, c in zip(qubits, conserved) if not c]
         if len(mixing) > self.n_local:
@@ -259,6 +312,7 @@ class ShardedState:
         self._bit(q0), self._bit(q1)
         if q0 == q1:
             raise ValueError("Indices must be distinct.")
+        self._advance_plan([q0, q1])
         b0, b1 = self.n - 1 - q0, self.n - 1 - q1
         self.phys[b0], self.phys[b1] = self.phys[b1], self.phys[b0]
         return self
@@ -266,6 +320,7 @@ class ShardedState:
     def apply_mcphase(self, qubits, phase: complex) -> "ShardedState":
         """Multiply the amplitudes whose ``qubits`` are all 1 by ``phase``: never any traffic."""
         bits = [self._bit(int(q)) for q in qubits]
+        self._advance_plan([int(q) for q in qubits])
         if any(self._rank_bit(b) == 0 for b in bits if b >= self.n_local):
             return self
         local = [self._local_qubit(b) for b in bits if b < self.n_local]
@@ -286,6 +341,7 @@ class ShardedState:
         diagonal = u[0, 1] == 0 and u[1, 0] == 0
         for q in controls + [target]:
             self._bit(q)
+        self._advance_plan(controls + [target])
         if not diagonal:
             self._localise_all([target], controls)
         cbits = [self._bit(c) for c in controls]
@@ -331,6 +387,7 @@ class ShardedState:
         self.phys = [p - 1 if p > b else p for p in self.phys]
         self.n -= 1
         self.n_local -= 1
+        self._plan = None                       # the qubits are renumbered: any look-ahead is stale
         self.buf = self.buf[: 1 << self.n_local]
         return self
 

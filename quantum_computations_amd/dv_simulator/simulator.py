@@ -71,6 +71,8 @@ class Simulator:
             self.launch_list = fuse_circuit(self.circuit, self._fuse)
         else:
             self.launch_list = self.circuit
+        if hasattr(dev, "prepare"):
+            dev.prepare(self.launch_list)     # sharded registers plan their qubit exchanges over the whole circuit
         for gate in self.launch_list:
             if isinstance(gate, ClassicalControl):
                 if not gate.eval(self.results):

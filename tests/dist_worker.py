@@ -106,6 +106,30 @@ def main():
         assert st.exchanges > 0, "a depth-80 circuit must touch a remote qubit"
         assert abs(st.norm2() - 1.0) < 1e-12
 
+    # 1b. look-ahead eviction (prepare): same final state, no more exchanges than the default choice
+    ops = W.random_circuit(n, 120, 21)
+    ket = W.random_ket(n, 21)
+    want, _ = O.run_circuit(ops, ket)
+    counts = {}
+    for planned in (False, True):
+        st = make_state(n, ket, args.backend, device)
+        gates = W.to_gates(ops)
+        if planned:
+            out = Simulator(gates).run(st)            # Simulator.run announces the circuit to the register
+        else:
+            for gate in gates:
+                gate.apply(st)
+            out = st
+        check(f"look-ahead={planned}", out.to_numpy(), want)
+        counts[planned] = st.exchanges
+    assert counts[True] <= counts[False], counts
+    # a gate outside the announced circuit only switches the look-ahead off
+    st = make_state(n, ket, args.backend, device)
+    st.prepare(W.to_gates(ops))
+    G.H(n - 1).apply(st)
+    assert st._plan is None
+    check("off-plan gate", st.to_numpy(), O.apply_gate(ket, G.H(0).matrix, [n - 1]))
+
     # 2. the remote-qubit CX mix of BASELINE config 3: global->local, local->global, global->global
     ket = W.random_ket(n, 3)
     st = make_state(n, ket, args.backend, device)
@@ -175,7 +199,8 @@ def main():
 
     dist.barrier()
     if rank == 0:
-        print(f"dist_worker ok: world={world} backend={args.backend} n={n} cx_exchanges={exchanges_cx}")
+        print(f"dist_worker ok: world={world} backend={args.backend} n={n} cx_exchanges={exchanges_cx} "
+              f"exchanges_120_gates default={counts[False]} look-ahead={counts[True]}")
     dist.destroy_process_group()
 
 
