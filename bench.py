@@ -88,6 +88,12 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the gate path has no CPU fallback")
+    # Development aid only (never set by the driver): QSV_BENCH_ONE_GPU=1 lets N ranks share GPU 0 with the
+    # collectives staged through host memory over gloo (tests/host_staged.py), to rehearse the N > 1 code path on
+    # a one-GPU box.  Its numbers are meaningless as a measurement.
+    one_gpu_rehearsal = world > 1 and os.environ.get("QSV_BENCH_ONE_GPU") == "1"
+    if one_gpu_rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     from quantum_computations_amd import workloads as W
@@ -111,12 +117,23 @@ def main():
         import torch.distributed as dist
         from quantum_computations_amd.distributed import ShardedState
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dev = ShardedState.random(n, seed=STATE_SEED, device=local_rank)
+        if one_gpu_rehearsal:
+            sys.path.insert(0, str(REPO / "tests"))
+            from host_staged import HostStagedShardedState
+            from quantum_computations_amd.distributed import _default_engine_factory
+            dist.init_process_group("gloo")
+            buf = torch.empty(1 << n_local, dtype=torch.complex128, device="cuda:0")
+            dev = HostStagedShardedState(n, buf, _default_engine_factory(0))
+            dev.fill_random(STATE_SEED)
+            reduce_device = "cpu"
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dev = ShardedState.random(n, seed=STATE_SEED, device=local_rank)
+            reduce_device = "cuda"
         barrier = dist.barrier
 
         def reduce_max(x):
-            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            t = torch.tensor([x], dtype=torch.float64, device=reduce_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         comm_info = {}
@@ -183,6 +200,9 @@ def main():
             "unit_note": "value = gate-apps/s on the full register x 2^(n-28): 28-qubit gate-app equivalents",
         },
         "gate_apps_per_sec_on_register": register_rate,
+        **({"half_shard_exchanges_per_step": getattr(dev, "exchanges", 0) / max(1, args.steps + args.warmup),
+            "exchange": "two-phase all_to_all over all xGMI links" if world >= 4 else "pairwise send/recv"}
+           if world > 1 else {}),
         "algorithmic_GBps_per_gpu": bytes_per_gate_per_gpu * register_rate / 1e9,
     }
     if record:

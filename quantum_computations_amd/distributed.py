@@ -79,6 +79,7 @@ class ShardedState:
         self.bytes_sent = 0
         self._plan = None                                 # look-ahead set by prepare(): [(indices, mixing qubits)]
         self._cursor = 0
+        self.multipath = True                             # route exchanges over all links (see _exchange)
 
     # ---- construction ---------------------------------------------------------------------------
     @classmethod
@@ -152,13 +153,30 @@ class ShardedState:
     # The three collectives the register needs.  Kept as small methods so that a test can stage them through
     # host memory (gloo on a box with fewer GPUs than ranks); production uses them as written, on RCCL.
     def _exchange(self, send, recv, peer: int) -> None:
-        """Simultaneous send of ``send`` to ``peer`` and receive of ``recv`` from it (grouped ncclSend/ncclRecv)."""
+        """Deliver ``send`` to ``peer`` and receive its ``send`` into ``recv``.  Every rank calls this in the same
+        step with the same rank mask (``peer = rank ^ mask``), which is what makes the multi-path form legal.
+
+        xGMI is point to point: the direct link to ``peer`` is one of seven, so a plain send/recv pair leaves 6/7 of
+        a GPU's links idle.  With 4 or more ranks the half shard is therefore cut into ``world`` chunks that travel
+        over *all* links: chunk y goes to rank y first (one ``all_to_all_single``), every rank hands the chunks it
+        holds for x over to ``x ^ mask`` (a second ``all_to_all_single``), and each directed link carries one chunk
+        per phase -- world/2 times less time than the direct transfer.  ``send`` is overwritten (its content has
+        left the rank by then)."""
         import torch
 
         dist = self._dist
-        peer_global = dist.get_global_rank(self.group, peer) if self.group is not None else peer
         # RCCL has no complex dtype: move the amplitudes as (re, im) float64 pairs (same bytes, no copy)
         send_r, recv_r = torch.view_as_real(send), torch.view_as_real(recv)
+        if self.multipath and self.world >= 4 and send.numel() % self.world == 0:
+            mask = self.rank ^ peer
+            dist.all_to_all_single(recv_r, send_r, group=self.group)        # phase 1: chunk y -> rank y
+            relay = recv_r.view(self.world, -1)
+            staged = send_r.view(self.world, -1)
+            order = torch.tensor([z ^ mask for z in range(self.world)], device=send.device)
+            torch.index_select(relay, 0, order, out=staged)                 # slot z <- chunk held for z ^ mask
+            dist.all_to_all_single(recv_r, send_r, group=self.group)        # phase 2: hand over to the owners
+            return
+        peer_global = dist.get_global_rank(self.group, peer) if self.group is not None else peer
         ops = [dist.P2POp(dist.isend, send_r, peer_global, self.group),
                dist.P2POp(dist.irecv, recv_r, peer_global, self.group)]
         for work in dist.batch_isend_irecv(ops):

@@ -31,27 +31,7 @@ from quantum_computations_amd.dv_simulator.simulator import Simulator  # noqa: E
 TOL = 1e-12
 
 
-class HostStagedShardedState(ShardedState):
-    """The production register (HBM shards, HIP kernels) with the three collectives staged through host memory
-    over gloo: lets several ranks share ONE GPU in a test, where RCCL refuses duplicate devices."""
-
-    def _exchange(self, send, recv, peer):
-        send_h, recv_h = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
-        ops = [dist.P2POp(dist.isend, send_h, peer), dist.P2POp(dist.irecv, recv_h, peer)]
-        for work in dist.batch_isend_irecv(ops):
-            work.wait()
-        recv.copy_(recv_h)
-
-    def _allreduce_sum(self, values):
-        t = torch.tensor(values, dtype=torch.float64)
-        dist.all_reduce(t)
-        return [float(v) for v in t]
-
-    def _allgather_shards(self):
-        mine = self.buf.cpu().contiguous()
-        shards = [torch.empty_like(mine) for _ in range(self.world)]
-        dist.all_gather(shards, mine)
-        return torch.cat(shards).numpy()
+from host_staged import HostStagedShardedState  # noqa: E402
 
 
 def make_state(n, ket, backend, device):

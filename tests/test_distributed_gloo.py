@@ -33,7 +33,8 @@ def run_workers(world: int, *extra: str, timeout: int = 600) -> str:
     return proc.stdout
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_register_matches_oracle(world):
-    out = run_workers(world, "--backend", "gloo", "--qubits", "9")
+    """world 2: direct send/recv pairs; world 4 and 8: the two-phase all-to-all (multi-path) exchange."""
+    out = run_workers(world, "--backend", "gloo", "--qubits", "9" if world < 8 else "10")
     assert f"dist_worker ok: world={world}" in out
