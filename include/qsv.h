@@ -142,6 +142,12 @@ int qsv_apply_mode2_diag(qsv_state *st, int mode0, int mode1, const double *diag
  * plane that BS and CX do per bond pair with RegularGridInterpolator (cv_simulator/gates.py:74-80,187-189)
  * is nnz = 4; SWAP (gates.py:48-55) is nnz = 1. */
 int qsv_apply_mode2_gather(qsv_state *st, int mode0, int mode1, int nnz, const int32_t *cols, const double *vals);
+/* Block-diagonal two-mode operator, in place: `nblocks` disjoint sets of (d, d)-plane points, set k holding
+ * sizes[k] (<= 32) points listed in plane_indices (= j0*d+j1 in (mode0, mode1) order, concatenated), mixed by
+ * the dense sizes[k] x sizes[k] complex matrix found at the matching position of `mats` (row-major, concatenated).
+ * Plane points in no block are left alone.  A Fock-basis beam splitter (it conserves n_a + n_b) is 2d-1 blocks. */
+int qsv_apply_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const int32_t *sizes,
+                           const int32_t *plane_indices, const double *mats);
 /* Homodyne read-out (Mq.apply, cv_simulator/gates.py:90-117): probs[j] = sum over the other modes of
  * |amp|^2 at level j of `mode` (the diagonal of partial_density_mps, mps.py:176-190, without the dq factors);
  * project keeps level `level` of `mode`, multiplies by `scale` and removes the mode. */

@@ -60,6 +60,7 @@ SIGNATURES: dict[str, list] = {
     "qsv_apply_mode2": [_state_p, C.c_int, C.c_int, C.c_void_p],
     "qsv_apply_mode2_diag": [_state_p, C.c_int, C.c_int, C.c_void_p],
     "qsv_apply_mode2_gather": [_state_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "qsv_apply_mode2_blocks": [_state_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "qsv_mode_marginal": [_state_p, C.c_int, C.c_void_p],
     "qsv_mode_project": [_state_p, C.c_int, C.c_int, C.c_double],
     "qsv_mode_insert": [_state_p, C.c_int, C.c_void_p],

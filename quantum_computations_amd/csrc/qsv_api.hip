@@ -658,6 +658,17 @@ int qsv_apply_mode2_gather(qsv_state *st, int mode0, int mode1, int nnz, const i
     return qsvq_mode2_gather(st, mode0, mode1, nnz, cols, vals);
 }
 
+int qsv_apply_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const int32_t *sizes,
+                           const int32_t *plane_indices, const double *mats) {
+    if (!valid(st) || !sizes || !plane_indices || !mats) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (nblocks < 1 || nblocks > (1 << 20)) return qsv_fail(QSV_EINVAL, "bad block count");
+    const int ms[2] = {mode0, mode1};
+    int rc = check_modes(st, 2, ms);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvq_mode2_blocks(st, mode0, mode1, nblocks, sizes, plane_indices, mats);
+}
+
 int qsv_mode_marginal(qsv_state *st, int mode, double *probs) {
     if (!valid(st) || !probs) return qsv_fail(QSV_EINVAL, "null pointer");
     int rc = check_modes(st, 1, &mode);

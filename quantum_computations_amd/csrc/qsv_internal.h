@@ -109,6 +109,8 @@ int qsvk_adopt(qsv_state *st, uint64_t new_amps);              // make the spare
 int qsvq_mode1(qsv_state *st, int mode, const double *m, bool diag);
 int qsvq_mode2(qsv_state *st, int mode0, int mode1, const double *m, bool diag);
 int qsvq_mode2_gather(qsv_state *st, int mode0, int mode1, int nnz, const int32_t *cols, const double *vals);
+int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const int32_t *sizes,
+                      const int32_t *plane_indices, const double *mats);
 int qsvq_mode_marginal(qsv_state *st, int mode, double *probs);
 int qsvq_mode_project(qsv_state *st, int mode, int level, double scale);
 int qsvq_mode_insert(qsv_state *st, int mode, const double *vec);

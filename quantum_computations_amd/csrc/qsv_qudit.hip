@@ -158,6 +158,43 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_mode2_gather(const amp_t *__restr
     }
 }
 
+// Block-diagonal two-mode operator, in place: the (d x d) plane splits into `nblocks` disjoint index sets, each mixed
+// by its own small dense matrix (a beam splitter conserves n_a + n_b: its blocks are the anti-diagonals of the Fock
+// plane, sizes 1..d).  A thread owns one plane (all other indices fixed; consecutive lanes = consecutive memory),
+// walks the blocks, holds a block's <= 32 amplitudes in registers and reads the block matrix and the plane offsets
+// with wave-uniform (scalar) loads.  sum_b s_b^2 complex FMAs per plane instead of d^4 for the dense operator.
+constexpr int MAX_BLOCK = 32;
+
+__global__ __launch_bounds__(QSV_BLOCK) void k_mode2_blocks(amp_t *__restrict__ a, uint64_t L, int d, uint64_t Mid,
+                                                           uint64_t R, int nblocks,
+                                                           const int32_t *__restrict__ sizes,
+                                                           const int64_t *__restrict__ mat_start,  // in complex entries
+                                                           const int32_t *__restrict__ idx_start,
+                                                           const uint64_t *__restrict__ plane_off,  // amplitude offsets
+                                                           const double *__restrict__ mats) {
+    const uint64_t planes = L * Mid * R;
+    const uint64_t p = blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x;
+    if (p >= planes) return;
+    const uint64_t r = p % R, m = (p / R) % Mid, l = p / (R * Mid);
+    amp_t *base = a + l * (R * d * Mid * d) + m * (R * d) + r;
+    for (int b = 0; b < nblocks; ++b) {
+        const int s = sizes[b];
+        const uint64_t *off = plane_off + idx_start[b];
+        const double *M = mats + 2 * mat_start[b];
+        amp_t x[MAX_BLOCK];
+#pragma unroll
+        for (int c = 0; c < MAX_BLOCK; ++c) x[c] = (c < s) ? base[off[c]] : amp_t{0.0, 0.0};
+        for (int row = 0; row < s; ++row) {
+            const double *mr = M + 2 * static_cast<size_t>(row) * s;
+            amp_t acc = {0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < MAX_BLOCK; ++c)
+                if (c < s) acc = cfma(cplx{mr[2 * c], mr[2 * c + 1]}, x[c], acc);
+            base[off[row]] = acc;
+        }
+    }
+}
+
 // probs[j] += sum over everything but the mode axis of |a[l, j, r]|^2.  One workgroup per (j, slice of l):
 // deterministic two-level sum (block partials [j][slice] summed on the host in index order).
 __global__ __launch_bounds__(QSV_BLOCK) void k_mode_marginal(const amp_t *__restrict__ a, uint64_t L, int d, uint64_t R,
@@ -378,6 +415,57 @@ int qsvq_mode2_gather(qsv_state *st, int mode0, int mode1, int nnz, const int32_
     rc = check_launch();
     if (rc) return rc;
     return adopt(st, fresh);
+}
+
+int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const int32_t *sizes,
+                      const int32_t *plane_indices, const double *mats) {
+    const uint64_t d = st->d;
+    const int a = mode0 < mode1 ? mode0 : mode1, b = mode0 < mode1 ? mode1 : mode0;
+    const uint64_t L = ipow(d, a), Mid = ipow(d, b - a - 1), R = ipow(d, st->n - 1 - b);
+    const uint64_t stride0 = mode0 < mode1 ? R * d * Mid : R, stride1 = mode0 < mode1 ? R : R * d * Mid;
+    std::vector<int64_t> mat_start(nblocks);
+    std::vector<int32_t> idx_start(nblocks);
+    int64_t mtot = 0;
+    int32_t itot = 0;
+    std::vector<uint8_t> seen(d * d, 0);
+    for (int k = 0; k < nblocks; ++k) {
+        if (sizes[k] < 1 || sizes[k] > MAX_BLOCK)
+            return qsv_fail(QSV_EINVAL, "block sizes must be in 1.." + std::to_string(MAX_BLOCK));
+        mat_start[k] = mtot;
+        idx_start[k] = itot;
+        mtot += static_cast<int64_t>(sizes[k]) * sizes[k];
+        itot += sizes[k];
+    }
+    std::vector<uint64_t> off(itot + MAX_BLOCK, 0);  // padded: the kernel's unrolled loads may look one block ahead
+    for (int32_t i = 0; i < itot; ++i) {
+        const int32_t pi = plane_indices[i];
+        if (pi < 0 || pi >= static_cast<int32_t>(d * d) || seen[pi]++)
+            return qsv_fail(QSV_EINVAL, "plane indices must be distinct and inside the (d, d) plane");
+        off[i] = (pi / d) * stride0 + (pi % d) * stride1;
+    }
+    // one device buffer: [mats | plane_off | mat_start | sizes | idx_start], every section 16-byte aligned
+    auto pad16 = [](size_t x) { return (x + 15) / 16 * 16; };
+    const size_t b_m = pad16(sizeof(double) * 2 * mtot), b_o = pad16(sizeof(uint64_t) * off.size()),
+                 b_s = pad16(sizeof(int64_t) * nblocks), b_z = pad16(sizeof(int32_t) * nblocks);
+    int rc = qsvk_ensure_matrix(st, b_m + b_o + b_s + 2 * b_z);
+    if (rc) return rc;
+    char *p = reinterpret_cast<char *>(st->dev_matrix);
+    double *d_m = reinterpret_cast<double *>(p);
+    uint64_t *d_o = reinterpret_cast<uint64_t *>(p + b_m);
+    int64_t *d_s = reinterpret_cast<int64_t *>(p + b_m + b_o);
+    int32_t *d_z = reinterpret_cast<int32_t *>(p + b_m + b_o + b_s);
+    int32_t *d_i = reinterpret_cast<int32_t *>(p + b_m + b_o + b_s + b_z);
+    QSV_HIP(hipMemcpyAsync(d_m, mats, sizeof(double) * 2 * mtot, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipMemcpyAsync(d_o, off.data(), sizeof(uint64_t) * off.size(), hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipMemcpyAsync(d_s, mat_start.data(), sizeof(int64_t) * nblocks, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipMemcpyAsync(d_z, sizes, sizeof(int32_t) * nblocks, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipMemcpyAsync(d_i, idx_start.data(), sizeof(int32_t) * nblocks, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));  // all sources are pageable host memory that dies at return
+    const uint64_t planes = L * Mid * R;
+    const int grid = grid_of(planes, QSV_BLOCK, 0x7fffffff);
+    hipLaunchKernelGGL(k_mode2_blocks, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, L, static_cast<int>(d),
+                       Mid, R, nblocks, d_z, d_s, d_i, d_o, d_m);
+    return check_launch();
 }
 
 int qsvq_mode_marginal(qsv_state *st, int mode, double *probs) {

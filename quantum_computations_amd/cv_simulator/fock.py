@@ -88,19 +88,33 @@ class Phase(SingleModeGate):
         state.reg.apply_mode(phase_matrix(state.d, -self.arg if self.dagger else self.arg), self.index)
 
 
-class BS(TwoModeGate):
-    """Beam splitter in the Fock basis.  ``dense=True`` applies the full d^2 x d^2 matrix; the default uses its
-    photon-number-conserving sparsity (<= d entries per row) through the gather kernel."""
+def photon_number_blocks(matrix: np.ndarray, d: int):
+    """Split a photon-number-conserving d^2 x d^2 operator into its 2d-1 anti-diagonal blocks:
+    ``[(plane_indices, block_matrix), ...]`` with ``plane_indices = n_a * d + n_b`` for ``n_a + n_b = N``."""
+    blocks = []
+    for total in range(2 * d - 1):
+        idx = [na * d + (total - na) for na in range(max(0, total - d + 1), min(d, total + 1))]
+        blocks.append((idx, matrix[np.ix_(idx, idx)]))
+    return blocks
 
-    def __init__(self, index1, index2, angle: float = np.pi / 4, *, dense: bool = False, **kwargs):
+
+class BS(TwoModeGate):
+    """Beam splitter in the Fock basis.  Default ``method="blocks"``: one small dense matrix per total photon
+    number, applied in place (``qsv_apply_mode2_blocks``).  ``"gather"`` uses the row-sparse form (<= d entries per
+    row), ``"dense"`` the full d^2 x d^2 matrix -- same result, kept for cross-checks."""
+
+    def __init__(self, index1, index2, angle: float = np.pi / 4, *, method: str = "blocks", dense: bool = False,
+                 **kwargs):
         super().__init__(index1, index2, arg=angle, **kwargs)
-        self.dense = dense
+        self.method = "dense" if dense else method
 
     def apply(self, state: FockState, **_):
         theta = -self.arg if self.dagger else self.arg
         m = beamsplitter_matrix(state.d, theta)
-        if self.dense:
+        if self.method == "dense":
             state.reg.apply_two_mode(m, self.index1, self.index2)
-        else:
+        elif self.method == "gather":
             cols, vals = sparse_rows(m, tol=1e-300)
             state.reg.apply_two_mode_gather(cols, vals, self.index1, self.index2)
+        else:
+            state.reg.apply_two_mode_blocks(photon_number_blocks(m, state.d), self.index1, self.index2)

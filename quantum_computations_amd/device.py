@@ -354,6 +354,16 @@ class QuditState:
                   C.c_void_p(cols.ctypes.data), _ptr(vals))
         return self
 
+    def apply_two_mode_blocks(self, blocks, mode0: int, mode1: int) -> "QuditState":
+        """Block-diagonal plane operator: ``blocks`` = list of ``(plane_indices, matrix)`` with disjoint index sets
+        (``j0 * d + j1`` in (mode0, mode1) order) and a dense ``s x s`` matrix each (s <= 32).  In place."""
+        sizes = np.array([len(idx) for idx, _ in blocks], dtype=np.int32)
+        indices = np.ascontiguousarray(np.concatenate([np.asarray(idx, dtype=np.int32) for idx, _ in blocks]))
+        mats = np.ascontiguousarray(np.concatenate([_cbuf(m, len(idx) ** 2).reshape(-1) for idx, m in blocks]))
+        _lib.call("qsv_apply_mode2_blocks", self._h, int(mode0), int(mode1), len(blocks),
+                  sizes.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p), _ptr(mats))
+        return self
+
     def marginal(self, mode: int) -> np.ndarray:
         """Sum of |amplitude|^2 over every other mode, per level of ``mode``."""
         _, d = self.dims
