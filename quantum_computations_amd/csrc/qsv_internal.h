@@ -30,6 +30,7 @@ struct GateArgs {
     uint64_t hoff[4];
     int32_t nins;
     uint32_t lane_ctrl;  // controls below QSV_LANE_BITS: a lane takes part iff (lane & lane_ctrl) == lane_ctrl
+    int32_t ubit;        // the U work items of a thread are 2^ubit items apart (8 = consecutive 256-item tiles)
     int32_t lbit[2];     // positions of the low target bits (bit j of l)
     int32_t lxor[4];     // lane xor mask of low-bit combination x
     uint8_t pos[QSV_MAX_INS];
@@ -72,6 +73,7 @@ struct qsv_state {
     int unroll = 0;
     int grid_cap = 0;
     int nontemporal = 1;
+    int ubit = 8;
     char last_kernel[96] = "";        // name of the most recent gate kernel launched (qsv_last_kernel)
 };
 

@@ -117,7 +117,10 @@ __device__ __forceinline__ void dense_body(amp_t *__restrict__ a, const GateArgs
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint64_t w = tile * TILE + static_cast<uint64_t>(u) * QSV_BLOCK + threadIdx.x;
+            // the U items of a thread sit 2^ubit work items apart (ubit = 8: back to back tiles of 256)
+            const uint64_t t = tile * QSV_BLOCK + threadIdx.x;
+            const uint64_t w = U == 1 ? t
+                                      : (((t >> g.ubit) * U + u) << g.ubit) | (t & ((1ull << g.ubit) - 1ull));
             ok[u] = w < g.W;  // W is a multiple of 64: uniform over the wave
             base[u] = deposit(w, g);
 #pragma unroll
@@ -585,12 +588,15 @@ int launch_dense(qsv_state *st, const GateArgs &g) {
     int U = st->unroll > 0 ? st->unroll : default_unroll<KH, KL>(g);
     // never more unrolling than there is work for one tile
     while (U > 1 && g.W < static_cast<uint64_t>(QSV_BLOCK) * U) U >>= 1;
+    GateArgs ga = g;
+    ga.ubit = st->ubit;
+    while (ga.ubit > 8 && (g.W >> ga.ubit) < static_cast<uint64_t>(U)) --ga.ubit;  // small registers
     const int grid = grid_for(g.W, QSV_BLOCK * U, st->grid_cap);
     switch (U) {
-        case 1: launch_dense_nt<KH, KL, 1>(st, g, grid); break;
-        case 2: launch_dense_nt<KH, KL, 2>(st, g, grid); break;
-        case 4: launch_dense_nt<KH, KL, 4>(st, g, grid); break;
-        default: launch_dense_nt<KH, KL, 8>(st, g, grid); break;
+        case 1: launch_dense_nt<KH, KL, 1>(st, ga, grid); break;
+        case 2: launch_dense_nt<KH, KL, 2>(st, ga, grid); break;
+        case 4: launch_dense_nt<KH, KL, 4>(st, ga, grid); break;
+        default: launch_dense_nt<KH, KL, 8>(st, ga, grid); break;
     }
     return check_launch();
 }

@@ -1,85 +1,104 @@
-"""Abstract gate API of the CV simulator -- mirror of ``simulators/cv_simulator/gate_abc.py:15-100``.
+"""Base classes of the CV gate API (the surface of ``simulators/cv_simulator/gate_abc.py:15-100``).
 
-Same classes, constructor signatures and error behaviour: parametrised gates take ``arg`` / ``dagger`` plus truncation
-keywords (accepted for compatibility, unused by the dense register); unknown keywords are logged, not raised;
-two-mode gates act on nearest neighbours only.
+What a caller of the reference relies on, and what is kept here:
+
+* ``Gate(arg=None, dagger=False, **svd_options)`` -- truncation keywords (``max_bond_dim``, ``abs_err``, ``rel_err``,
+  ``rng_seed``) are collected in ``gate.svd_options`` (the dense register ignores them), anything else is *logged*, never
+  raised; ``repr`` is ``Name(arg)^†``.
+* ``SingleModeGate(index, ...)`` -- ``index`` must be an ``int``; ``repr`` appends ``_index``.
+* ``Measurement(index, result=None, ...)`` -- ``dagger`` is meaningless and dropped with an INFO message.
+* ``TwoModeGate(index1, index2, ...)`` -- integer nearest neighbours only; exposes ``left_index < right_index``.
+* ``MeasurementResult(result, probability)``.
+* ``apply(register, **kwargs)`` mutates the register in place; unknown keyword arguments (``rng=...``) are ignored.
 """
 from __future__ import annotations
 
 import logging
-from abc import ABC, abstractmethod
-from typing import Any
 
 from .mps import MPS, SVD_OPTIONS
 
 logger = logging.getLogger(__name__)
 
+#: digits shown for floating-point gate arguments in ``repr``
 REPR_DIGITS = 5
+
+__all__ = ["REPR_DIGITS", "MeasurementResult", "Gate", "SingleModeGate", "Measurement", "TwoModeGate"]
+
+
+def _shown(value) -> str:
+    return str(round(value, REPR_DIGITS) if isinstance(value, float) else value)
+
+
+def _require_int(owner, *values, message: str) -> None:
+    if not all(isinstance(v, int) for v in values):
+        raise ValueError(f"{type(owner).__name__} {message}")
 
 
 class MeasurementResult:
+    """Outcome of a homodyne measurement: the grid value read off and its probability density."""
+
+    __slots__ = ("result", "probability")
+
     def __init__(self, result: float, probability: float):
-        self.result: float = result
-        self.probability: float = probability
+        self.result, self.probability = result, probability
 
     def __repr__(self):
-        return str(self.result)
+        return f"{self.result}"
 
 
-class Gate(ABC):
-    def __init__(self, arg: Any = None, dagger: bool = False, **kwargs):
-        self.arg = arg
-        self.dagger = dagger
-        self.svd_options = {key: kwargs.pop(key) for key in SVD_OPTIONS if key in kwargs}
-        if kwargs:
-            logger.warning(f"{type(self).__name__} recieved unexpected keyword arguments: {kwargs.keys()}")
+class Gate:
+    """Anything with an in-place ``apply(register, **kwargs)``; subclasses implement it."""
+
+    def __init__(self, arg=None, dagger: bool = False, **keywords):
+        self.arg, self.dagger = arg, dagger
+        self.svd_options = {name: keywords.pop(name) for name in tuple(keywords) if name in SVD_OPTIONS}
+        if keywords:
+            logger.warning("%s recieved unexpected keyword arguments: %s", type(self).__name__, keywords.keys())
+
+    def _label(self) -> str:
+        text = type(self).__name__
+        if self.arg is not None:
+            text += f"({_shown(self.arg)})"
+        return text + "^†" * bool(self.dagger)
 
     def __repr__(self):
-        arg = round(self.arg, REPR_DIGITS) if isinstance(self.arg, float) else self.arg
-        return type(self).__name__ + (f"({arg})" if arg is not None else "") + ("^†" if self.dagger else "")
+        return self._label()
 
-    @abstractmethod
-    def apply(self, mps: MPS, **kwargs) -> None | MeasurementResult:
-        """Apply the gate to ``mps`` in place; measurements return their result.  Keyword arguments a gate does
-        not use (e.g. ``rng``) are ignored silently."""
+    def apply(self, mps: MPS, **kwargs):
+        raise NotImplementedError(f"{type(self).__name__} does not define apply()")
 
 
 class SingleModeGate(Gate):
-    def __init__(self, index: int, **kwargs):
-        super().__init__(**kwargs)
-        if not isinstance(index, int):
-            raise ValueError(f"{type(self).__name__} requires a single integer index.")
+    def __init__(self, index: int, **keywords):
+        Gate.__init__(self, **keywords)
+        _require_int(self, index, message="requires a single integer index.")
         self.index = index
 
     def __repr__(self):
-        return super().__repr__() + f"_{self.index}"
+        return f"{self._label()}_{self.index}"
 
 
 class Measurement(SingleModeGate):
-    def __init__(self, index, result: float = None, **kwargs):
-        if kwargs.pop("dagger", None):
-            logger.info(type(self).__name__ + "gates ignores adjoint/dagger.")
-        super().__init__(index, **kwargs)
-        self.result: float = result
+    def __init__(self, index, result: float = None, **keywords):
+        if keywords.pop("dagger", False):
+            logger.info("%s gates ignore adjoint/dagger.", type(self).__name__)
+        SingleModeGate.__init__(self, index, **keywords)
+        self.result = result
 
     def __repr__(self):
-        return super().__repr__() + (f" = {round(self.result, REPR_DIGITS)}" if self.result else "")
-
-    @abstractmethod
-    def apply(self, mps: MPS, **kwargs) -> MeasurementResult:
-        pass
+        tail = f" = {_shown(self.result)}" if self.result else ""
+        return SingleModeGate.__repr__(self) + tail
 
 
 class TwoModeGate(Gate):
-    def __init__(self, index1: int, index2: int, **kwargs):
-        super().__init__(**kwargs)
-        if not isinstance(index1, int) or not isinstance(index2, int):
-            raise ValueError(f"{type(self).__name__} requires exactly two indices.")
+    def __init__(self, index1: int, index2: int, **keywords):
+        Gate.__init__(self, **keywords)
+        _require_int(self, index1, index2, message="requires exactly two indices.")
         if abs(index1 - index2) != 1:
             raise ValueError(f"{type(self).__name__} can only be applied to neighbours, but indices: "
                              f"{(index1, index2)} were given.")
         self.index1, self.index2 = index1, index2
-        self.left_index, self.right_index = sorted([index1, index2])
+        self.left_index, self.right_index = min(index1, index2), max(index1, index2)
 
     def __repr__(self):
-        return super().__repr__() + f"_{self.index1},{self.index2}"
+        return f"{self._label()}_{self.index1},{self.index2}"

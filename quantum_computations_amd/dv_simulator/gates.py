@@ -149,27 +149,16 @@ class RZ(SingleQubitGate):
         return super().__repr__() + f"({round(self.angle, REPR_DIGITS)})"
 
 
-class CX(TwoQubitGate):
-    def __init__(self, control, target):
-        super().__init__(control, target, npq.CX)
-
-    @property
-    def control(self):
-        return self.indices[0]
-
-    @property
-    def target(self):
-        return self.indices[1]
+def _fixed_2q(name: str, matrix_of, doc: str, **extra):
+    def __init__(self, first, second):
+        TwoQubitGate.__init__(self, first, second, matrix_of())
+    return type(name, (TwoQubitGate,), {"__init__": __init__, "__doc__": doc, "__module__": __name__, **extra})
 
 
-class CZ(TwoQubitGate):
-    def __init__(self, index1, index2):
-        super().__init__(index1, index2, npq.CZ)
-
-
-class SWAP(TwoQubitGate):
-    def __init__(self, index1, index2):
-        super().__init__(index1, index2, npq.SWAP)
+CX = _fixed_2q("CX", lambda: npq.CX, "Controlled X: ``CX(control, target)``; kept as a pure amplitude move on the GPU.",
+               control=property(lambda self: self.indices[0]), target=property(lambda self: self.indices[1]))
+CZ = _fixed_2q("CZ", lambda: npq.CZ, "Controlled Z (symmetric): touches a quarter of the register.")
+SWAP = _fixed_2q("SWAP", lambda: npq.SWAP, "Exchange of two qubits.")
 
 
 class Insert(SingleQubitGate):
