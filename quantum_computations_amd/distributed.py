@@ -32,6 +32,9 @@ def _default_engine_factory(device: int):
     return make
 
 
+_SWAP = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=np.complex128)
+
+
 def _leg_is_block_diagonal(m: np.ndarray, k: int, leg: int) -> bool:
     """True if the 2^k x 2^k matrix never maps leg = a to leg = b != a (so the leg's bit value is conserved)."""
     t = m.reshape((2,) * (2 * k))
@@ -294,6 +297,8 @@ class ShardedState:
             raise ValueError("Indices must be distinct.")
         for q in qubits:
             self._bit(q)
+        if k == 2 and np.array_equal(m, _SWAP):
+            return self.apply_swap(*qubits)           # a relabelling of the qubit map: no data moves
         self._advance_plan(qubits)
         conserved = [_leg_is_block_diagonal(m, k, j) for j in range(k)]
         mixing = [q for q, c in zip(qubits, conserved) if not c]
