@@ -43,9 +43,8 @@ def cpu_baseline(ops, dev, n, budget_s=12.0):
     """Time the C/OpenMP oracle on a prefix of the circuit, then use the result as a full-size parity check."""
     from oracle import c_oracle   # checker / baseline only -- never on the product path
 
-    os.environ.setdefault("OMP_NUM_THREADS", str(min(CPU_THREADS, len(os.sched_getaffinity(0)))))
-    c_oracle.load()
-    threads = int(os.environ["OMP_NUM_THREADS"])
+    want = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(CPU_THREADS, len(os.sched_getaffinity(0)))
+    threads = c_oracle.threads(want)            # omp_set_num_threads + omp_get_max_threads: what really runs
     host = dev.to_numpy()                       # the same initial state the GPU starts from
     t_total, done = 0.0, 0
     for op in ops:

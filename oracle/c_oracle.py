@@ -33,9 +33,16 @@ def load() -> C.CDLL:
         _lib.oracle_dense_matvec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib.oracle_norm2.argtypes = [C.c_void_p, C.c_int]
         _lib.oracle_norm2.restype = C.c_double
+        _lib.oracle_threads.argtypes = [C.c_int]
+        _lib.oracle_threads.restype = C.c_int
         for f in (_lib.oracle_apply_1q, _lib.oracle_apply_2q, _lib.oracle_dense_matvec):
             f.restype = None
     return _lib
+
+
+def threads(requested: int = 0) -> int:
+    """Set (if > 0) and return the OpenMP thread count of the C oracle."""
+    return int(load().oracle_threads(int(requested)))
 
 
 def apply_gate_inplace(state: np.ndarray, matrix: np.ndarray, indices: list[int]) -> None:

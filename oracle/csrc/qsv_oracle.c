@@ -12,6 +12,7 @@
  * Never linked into libqsv.so; built into oracle/libqsv_oracle.so by oracle/Makefile.
  */
 #include <complex.h>
+#include <omp.h>
 #include <stdint.h>
 
 typedef double _Complex cplx;
@@ -69,6 +70,13 @@ void oracle_dense_matvec(const double *u_, const double *in_, double *out_, int 
         for (uint64_t c = 0; c < dim; ++c) acc += u[r * dim + c] * in[c];
         out[r] = acc;
     }
+}
+
+/* Set (if requested > 0) and report the number of OpenMP threads the loops above use: bench.py states it as
+ * cpu_baseline.cores.  (Setting OMP_NUM_THREADS from Python is too late once an OpenMP runtime is loaded.) */
+int oracle_threads(int requested) {
+    if (requested > 0) omp_set_num_threads(requested);
+    return omp_get_max_threads();
 }
 
 double oracle_norm2(const double *state, int n) {
