@@ -81,6 +81,29 @@ def cv_fock(n_modes: int = 6, d: int = 32, gates: int = 60) -> dict:
             "BS_ms_by_pair": {f"({i},{i + 1})": float(np.mean(per_gate["BS"][i::n_modes - 1])) for i in range(n_modes - 1)}}
 
 
+def literal_dense(n: int = 12) -> dict:
+    """the reference's literal algorithm (dense 2^N x 2^N operator by kron + permutation, then a
+    mat-vec) restated with the package's small-N host helpers, timed on THIS host to calibrate it against the build
+    container where the real reference was timed."""
+    import statistics
+
+    from quantum_computations_amd.dv_simulator import numpy_quantum as npq
+    rng = np.random.default_rng(0)
+    ket = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    out = {}
+    for name, matrix, targets in [("H", npq.H, [n // 2]), ("T", npq.axis_rotation(np.pi / 4, [0, 0, 1]), [n // 2]),
+                                  ("CX", npq.CX, [1, n - 2])]:
+        times = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            full = npq.expand_gate(matrix, n, targets)
+            _ = full @ ket
+            times.append(time.perf_counter() - t0)
+        out[name + "_ms"] = 1e3 * statistics.median(times[1:])
+    return {"config": f"literal dense algorithm (expand_gate + mat-vec) at n={n} on this host, NumPy "
+                      f"{np.__version__}, {len(__import__('os').sched_getaffinity(0))} cores visible", **out}
+
+
 def pcie(n: int = 28) -> dict:
     dev = DeviceState.random(n, 1)
     t0 = time.perf_counter()
@@ -102,7 +125,7 @@ def main():
     ap.add_argument("--skip-cv", action="store_true")
     args = ap.parse_args()
     results = []
-    for fn, a in [(pcie, ()), (grover, (args.grover_n, 8))] + ([] if args.skip_cv else [(cv_fock, ())]):
+    for fn, a in [(pcie, ()), (literal_dense, ()), (grover, (args.grover_n, 8))] + ([] if args.skip_cv else [(cv_fock, ())]):
         t0 = time.time()
         r = fn(*a)
         r["wall_s"] = time.time() - t0
