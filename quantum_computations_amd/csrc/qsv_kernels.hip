@@ -312,36 +312,38 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_dense_big(amp_t *__restrict__ a, 
                                                         const double *__restrict__ M,
                                                         const uint64_t *__restrict__ hoff) {
     constexpr int D = 1 << K;
-    const uint64_t w = blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x;
-    if (w >= g.W) return;  // W is a multiple of 64 whenever KL > 0: whole waves leave together
-    const uint64_t base = deposit(w, g);
-    amp_t x[D];
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * QSV_BLOCK;
+    // W and the stride are multiples of 64 whenever KL > 0: whole waves enter and leave the loop together
+    for (uint64_t w = blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x; w < g.W; w += stride) {
+        const uint64_t base = deposit(w, g);
+        amp_t x[D];
 #pragma unroll
-    for (int c = 0; c < D; ++c) x[c] = ld<NT>(a + base + hoff[c]);
-    if constexpr (KL == 0) {
+        for (int c = 0; c < D; ++c) x[c] = ld<NT>(a + base + hoff[c]);
+        if constexpr (KL == 0) {
 #pragma unroll 1
-        for (int r = 0; r < D; ++r) {
-            const double *row = M + 2 * D * r;
-            amp_t acc = {0.0, 0.0};
+            for (int r = 0; r < D; ++r) {
+                const double *row = M + 2 * D * r;
+                amp_t acc = {0.0, 0.0};
 #pragma unroll
-            for (int c = 0; c < D; ++c) acc = cfma(cplx{row[2 * c], row[2 * c + 1]}, x[c], acc);
-            st<NT>(a + base + hoff[r], acc);  // in place: every input of this group is already in registers
+                for (int c = 0; c < D; ++c) acc = cfma(cplx{row[2 * c], row[2 * c + 1]}, x[c], acc);
+                st<NT>(a + base + hoff[r], acc);  // in place: every input of this group is already in registers
+            }
+        } else {
+            const int lane = threadIdx.x & 63;
+            wave_transpose<D, KL>(x, g, lane);
+            amp_t y[D];
+#pragma unroll
+            for (int r = 0; r < D; ++r) {
+                const double *row = M + 2 * D * r;
+                amp_t acc = {0.0, 0.0};
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc = cfma(cplx{row[2 * c], row[2 * c + 1]}, x[c], acc);
+                y[r] = acc;
+            }
+            wave_transpose<D, KL>(y, g, lane);
+#pragma unroll
+            for (int c = 0; c < D; ++c) st<NT>(a + base + hoff[c], y[c]);
         }
-    } else {
-        const int lane = threadIdx.x & 63;
-        wave_transpose<D, KL>(x, g, lane);
-        amp_t y[D];
-#pragma unroll
-        for (int r = 0; r < D; ++r) {
-            const double *row = M + 2 * D * r;
-            amp_t acc = {0.0, 0.0};
-#pragma unroll
-            for (int c = 0; c < D; ++c) acc = cfma(cplx{row[2 * c], row[2 * c + 1]}, x[c], acc);
-            y[r] = acc;
-        }
-        wave_transpose<D, KL>(y, g, lane);
-#pragma unroll
-        for (int c = 0; c < D; ++c) st<NT>(a + base + hoff[c], y[c]);
     }
 }
 
@@ -528,7 +530,9 @@ int grid_for(uint64_t items, int per_block, int cap) {
     uint64_t blocks = (items + per_block - 1) / per_block;
     if (blocks < 1) blocks = 1;
     if (cap > 0 && blocks > static_cast<uint64_t>(cap)) blocks = cap;
-    if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+    // an AQL dispatch counts work-ITEMS in 32 bits: at most 2^32 / 256 workgroups of 256 threads per launch
+    // (a 33-qubit register would need 2^25); every kernel launched through here loops over the remainder
+    if (blocks > 0x00ffffffull) blocks = 0x00ffffffull;
     return static_cast<int>(blocks);
 }
 

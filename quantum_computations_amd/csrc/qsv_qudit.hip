@@ -173,8 +173,8 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_mode2_blocks(amp_t *__restrict__ 
                                                            const uint64_t *__restrict__ plane_off,  // amplitude offsets
                                                            const double *__restrict__ mats) {
     const uint64_t planes = L * Mid * R;
-    const uint64_t p = blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x;
-    if (p >= planes) return;
+    for (uint64_t p = blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x; p < planes;
+         p += static_cast<uint64_t>(gridDim.x) * QSV_BLOCK) {
     const uint64_t r = p % R, m = (p / R) % Mid, l = p / (R * Mid);
     amp_t *base = a + l * (R * d * Mid * d) + m * (R * d) + r;
     for (int b = 0; b < nblocks; ++b) {
@@ -192,6 +192,7 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_mode2_blocks(amp_t *__restrict__ 
                 if (c < s) acc = cfma(cplx{mr[2 * c], mr[2 * c + 1]}, x[c], acc);
             base[off[row]] = acc;
         }
+    }
     }
 }
 
@@ -462,7 +463,7 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
     QSV_HIP(hipMemcpyAsync(d_i, idx_start.data(), sizeof(int32_t) * nblocks, hipMemcpyHostToDevice, st->stream));
     QSV_HIP(hipStreamSynchronize(st->stream));  // all sources are pageable host memory that dies at return
     const uint64_t planes = L * Mid * R;
-    const int grid = grid_of(planes, QSV_BLOCK, 0x7fffffff);
+    const int grid = grid_of(planes, QSV_BLOCK, 0x00ffffff);
     hipLaunchKernelGGL(k_mode2_blocks, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, L, static_cast<int>(d),
                        Mid, R, nblocks, d_z, d_s, d_i, d_o, d_m);
     return check_launch();

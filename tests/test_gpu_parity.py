@@ -399,6 +399,41 @@ def test_full_size_28q_round_trip_and_known_answers():
     assert abs(out_state.probabilities([(1 << (n - 1)) - 1])[0] - 1.0) < 1e-12
 
 
+def test_33_qubit_register_uses_64_bit_indices():
+    """128 GiB register: amplitude indices beyond 2^32 (the 34-qubit config shards to 2^31 amplitudes per GPU; this
+    exercises the same index arithmetic on one device).  Known answers only -- no host copy of the state exists."""
+    n = 33
+    try:
+        dev = DeviceState.zeros(n)
+    except MemoryError:
+        pytest.skip("not enough free HBM for a 128 GiB register")
+    top = 1 << (n - 1)
+    G.X(0).apply(dev)                                   # |10...0>: index 2^32
+    assert dev.probabilities([top])[0] == 1.0 and dev.probabilities([0])[0] == 0.0
+    G.CX(0, n - 1).apply(dev)                           # control on bit 32 flips bit 0
+    assert dev.probabilities([top + 1])[0] == 1.0
+    G.SWAP(0, 5).apply(dev)                             # bit 32 <-> bit 27
+    assert dev.probabilities([(1 << 27) + 1])[0] == 1.0
+    G.CZ(5, n - 1).apply(dev)                           # both bits set: global phase -1, probabilities unchanged
+    G.SWAP(5, 0).apply(dev)
+    assert dev.probabilities([top + 1])[0] == 1.0
+    for q in range(n):
+        G.H(q).apply(dev)
+    probe = [0, 1, top, top + 1, (1 << n) - 1, top + 123456789, 3 << 30]
+    assert maxdiff(dev.probabilities(probe), np.full(len(probe), 2.0 ** -n)) < 1e-24
+    assert abs(dev.norm2() - 1.0) < 1e-10
+    u = W.haar_unitary(4, np.random.default_rng(3))
+    dev.apply_matrix(u, [0, n - 1])                     # dense 2q on the highest and the lowest bit
+    dev.apply_matrix(np.conjugate(u).T, [0, n - 1])
+    assert maxdiff(dev.probabilities(probe), np.full(len(probe), 2.0 ** -n)) < 1e-24
+    for q in range(n):
+        G.H(q).apply(dev)
+    assert abs(dev.probabilities([top + 1])[0] - 1.0) < 1e-10
+    s_state, bit = G.MZ(0, result=1).apply(dev)          # 2^32 -> 2^31 amplitudes
+    assert bit == 1 and s_state.num_qubits == n - 1 and abs(s_state.probabilities([1])[0] - 1.0) < 1e-10
+    dev.close()
+
+
 # ---- sharded registers with the real HIP engine (ranks share the one GPU; collectives staged over gloo) -------
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_state_on_one_gpu(world):
