@@ -50,8 +50,10 @@ enum {
     QSV_OPT_UNROLL = 2,     /* work items in flight per thread (1,2,4,8); 0 = built-in default */
     QSV_OPT_GRID_CAP = 3,   /* max workgroups per launch; 0 = one tile per workgroup */
     QSV_OPT_NONTEMPORAL = 4, /* 1 (default): nontemporal loads/stores in the streaming kernels */
-    QSV_OPT_ITEM_STRIDE_BIT = 5 /* log2 of the distance (in work items) between the items one thread keeps in
-                                   flight when unroll > 1; default 8 = consecutive 4 KiB tiles */
+    QSV_OPT_ITEM_STRIDE_BIT = 5, /* log2 of the distance (in work items) between the items one thread keeps in
+                                    flight when unroll > 1; default 8 = consecutive 4 KiB tiles */
+    QSV_OPT_TILE_REGIONS = 6 /* tile order of the streaming kernels: R > 1 walks R contiguous regions of the register
+                                side by side (8 = one per XCD), 0 = plain order, -1 (default) = per-kernel choice */
 };
 
 typedef struct qsv_state qsv_state;

@@ -240,6 +240,10 @@ int qsv_set_option(qsv_state *st, int option, int64_t value) {
             st->grid_cap = static_cast<int>(value);
             return QSV_OK;
         case QSV_OPT_NONTEMPORAL: st->nontemporal = value != 0; return QSV_OK;
+        case QSV_OPT_TILE_REGIONS:
+            if (value < -1 || value > (1 << 20)) return qsv_fail(QSV_EINVAL, "tile regions must be -1, 0 or a count");
+            st->remap = static_cast<int>(value);
+            return QSV_OK;
         case QSV_OPT_ITEM_STRIDE_BIT:
             if (value < 8 || value > 24) return qsv_fail(QSV_EINVAL, "item stride bit must be in 8..24");
             st->ubit = static_cast<int>(value);

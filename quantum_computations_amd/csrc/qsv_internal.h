@@ -30,6 +30,7 @@ struct GateArgs {
     uint64_t hoff[4];
     int32_t nins;
     uint32_t lane_ctrl;  // controls below QSV_LANE_BITS: a lane takes part iff (lane & lane_ctrl) == lane_ctrl
+    int32_t remap;       // R > 1: tiles are walked as R contiguous regions side by side (R = 8: one per XCD)
     int32_t ubit;        // the U work items of a thread are 2^ubit items apart (8 = consecutive 256-item tiles)
     int32_t lbit[2];     // positions of the low target bits (bit j of l)
     int32_t lxor[4];     // lane xor mask of low-bit combination x
@@ -45,6 +46,7 @@ struct DiagArgs {
     int32_t nins;
     uint32_t lane_ctrl;
     int32_t b0, b1;
+    int32_t remap;
     uint8_t pos[QSV_MAX_INS];
     double d[8];
 };
@@ -74,6 +76,7 @@ struct qsv_state {
     int grid_cap = 0;
     int nontemporal = 1;
     int ubit = 8;
+    int remap = -1;                   // tile order: -1 = per-kernel default, 0 = plain, R = regions
     char last_kernel[96] = "";        // name of the most recent gate kernel launched (qsv_last_kernel)
 };
 

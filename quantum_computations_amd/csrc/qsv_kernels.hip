@@ -118,7 +118,12 @@ __device__ __forceinline__ void dense_body(amp_t *__restrict__ a, const GateArgs
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             // the U items of a thread sit 2^ubit work items apart (ubit = 8: back to back tiles of 256)
-            const uint64_t t = tile * QSV_BLOCK + threadIdx.x;
+            // tile order: with `remap` = R the launch walks R contiguous regions of the register side by side
+            // (workgroups are dealt round-robin over the 8 XCDs, so R = 8 gives every XCD its own region)
+            const uint64_t tile_eff = (g.remap > 1 && ntiles % g.remap == 0)
+                                          ? (tile % g.remap) * (ntiles / g.remap) + tile / g.remap
+                                          : tile;
+            const uint64_t t = tile_eff * QSV_BLOCK + threadIdx.x;
             const uint64_t w = U == 1 ? t
                                       : (((t >> g.ubit) * U + u) << g.ubit) | (t & ((1ull << g.ubit) - 1ull));
             ok[u] = w < g.W;  // W is a multiple of 64: uniform over the wave
@@ -180,7 +185,10 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_diag(amp_t *__restrict__ a, const
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint64_t w = tile * TILE + static_cast<uint64_t>(u) * QSV_BLOCK + threadIdx.x;
+            const uint64_t tile_eff = (g.remap > 1 && ntiles % g.remap == 0)
+                                          ? (tile % g.remap) * (ntiles / g.remap) + tile / g.remap
+                                          : tile;
+            const uint64_t w = tile_eff * TILE + static_cast<uint64_t>(u) * QSV_BLOCK + threadIdx.x;
             ok[u] = (w < g.W) && lane_ok;
             idx[u] = deposit(w, g);
             if (ok[u]) v[u] = ld<NT>(a + idx[u]);
@@ -594,6 +602,22 @@ int launch_dense(qsv_state *st, const GateArgs &g) {
     while (U > 1 && g.W < static_cast<uint64_t>(QSV_BLOCK) * U) U >>= 1;
     GateArgs ga = g;
     ga.ubit = st->ubit;
+    // measured on MI355X at n = 28 (profiles/r01_sweep_tile_order.txt): natural-order kernels like 32 regions,
+    // pair kernels 8 (one per XCD), except at pair strides of 16..512 MiB where the plain order is best
+    if (st->remap >= 0) {
+        ga.remap = st->remap;
+    } else {
+        bool far = false;
+        int top = 0;
+        for (int h = 1; h < (1 << KH); h <<= 1) {
+            int bit = 0;
+            while ((g.hoff[h] >> bit) > 1) ++bit;
+            far = far || (bit >= 20 && bit <= 25);
+            top = bit > top ? bit : top;
+        }
+        const bool sub = g.nins > KH || g.lane_ctrl != 0;  // controlled / pair-exchange launches: plain order
+        ga.remap = sub ? 0 : KH == 0 ? 32 : KH == 1 ? (far ? 0 : 8) : (top < 20 ? 8 : 0);
+    }
     while (ga.ubit > 8 && (g.W >> ga.ubit) < static_cast<uint64_t>(U)) --ga.ubit;  // small registers
     const int grid = grid_for(g.W, QSV_BLOCK * U, st->grid_cap);
     switch (U) {
@@ -605,7 +629,9 @@ int launch_dense(qsv_state *st, const GateArgs &g) {
     return check_launch();
 }
 
-int launch_diag(qsv_state *st, const DiagArgs &g) {
+int launch_diag(qsv_state *st, const DiagArgs &g0) {
+    DiagArgs g = g0;
+    g.remap = st->remap >= 0 ? st->remap : ((g0.nins == 0 && g0.lane_ctrl == 0) ? 32 : 0);
     int U = st->unroll > 0 ? st->unroll : 1;
     while (U > 1 && g.W < static_cast<uint64_t>(QSV_BLOCK) * U) U >>= 1;
     const dim3 gd(grid_for(g.W, QSV_BLOCK * U, st->grid_cap)), bd(QSV_BLOCK);
