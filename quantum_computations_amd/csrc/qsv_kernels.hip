@@ -592,6 +592,12 @@ int default_unroll(const GateArgs &g) {
         while ((g.hoff[h] >> bit) > 1) ++bit;
         far = far || (bit >= 20 && bit <= 25);
     }
+    if (KH == 1 && KL == 0 && far) {
+        // single far pair stride: only 16 MiB (bit 20) wants four items per thread (profiles/r01_sweep_far_bits.txt)
+        int bit = 0;
+        while ((g.hoff[1] >> bit) > 1) ++bit;
+        return bit == 20 ? 4 : 1;
+    }
     return far ? 4 : 1;
 }
 
@@ -616,7 +622,11 @@ int launch_dense(qsv_state *st, const GateArgs &g) {
             top = bit > top ? bit : top;
         }
         const bool sub = g.nins > KH || g.lane_ctrl != 0;  // controlled / pair-exchange launches: plain order
-        ga.remap = sub ? 0 : KH == 0 ? 32 : KH == 1 ? (far ? 0 : 8) : (top < 20 ? 8 : 0);
+        if (sub) ga.remap = 0;
+        else if (KH == 0) ga.remap = 32;
+        else if (KH == 1 && KL == 0) ga.remap = top == 20 ? 0 : top == 24 ? 2 : 8;  // per-stride winners of the sweeps
+        else if (KH == 1) ga.remap = far ? 0 : 8;
+        else ga.remap = top < 20 ? 8 : 0;
     }
     while (ga.ubit > 8 && (g.W >> ga.ubit) < static_cast<uint64_t>(U)) --ga.ubit;  // small registers
     const int grid = grid_for(g.W, QSV_BLOCK * U, st->grid_cap);
