@@ -641,8 +641,11 @@ int launch_dense(qsv_state *st, const GateArgs &g) {
 
 int launch_diag(qsv_state *st, const DiagArgs &g0) {
     DiagArgs g = g0;
-    g.remap = st->remap >= 0 ? st->remap : ((g0.nins == 0 && g0.lane_ctrl == 0) ? 32 : 0);
-    int U = st->unroll > 0 ? st->unroll : 1;
+    // full traffic: one item per thread, 32 regions; sub-space launches (Z, CZ, multi-controlled phases):
+    // four items per thread, one region per XCD (profiles/r01_sweep_sub_kernels.txt)
+    const bool sub = g0.nins > 0 || g0.lane_ctrl != 0;
+    g.remap = st->remap >= 0 ? st->remap : (sub ? 8 : 32);
+    int U = st->unroll > 0 ? st->unroll : (sub ? 4 : 1);
     while (U > 1 && g.W < static_cast<uint64_t>(QSV_BLOCK) * U) U >>= 1;
     const dim3 gd(grid_for(g.W, QSV_BLOCK * U, st->grid_cap)), bd(QSV_BLOCK);
     snprintf(st->last_kernel, sizeof(st->last_kernel), "k_diag<%d, %s>%s", U, st->nontemporal ? "true" : "false",
