@@ -295,6 +295,7 @@ struct BigArgs {
     int32_t nins;
     uint8_t pos[2 * QSV_MAX_K];  // ascending: high targets and stand-in bits
     uint64_t or_mask;            // unused (0); lets deposit() serve this struct too
+    uint64_t w0;                 // first work item of this launch (registers beyond 2^32 work items take several)
     int32_t lbit[QSV_MAX_K];     // lane-bit position of low target j (register index bit j)
 };
 
@@ -320,38 +321,38 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_dense_big(amp_t *__restrict__ a, 
                                                         const double *__restrict__ M,
                                                         const uint64_t *__restrict__ hoff) {
     constexpr int D = 1 << K;
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * QSV_BLOCK;
-    // W and the stride are multiples of 64 whenever KL > 0: whole waves enter and leave the loop together
-    for (uint64_t w = blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x; w < g.W; w += stride) {
-        const uint64_t base = deposit(w, g);
-        amp_t x[D];
+    // straight-line body (a grid-stride loop here cost the k = 5 transposed variants 4x: registers live across
+    // the back edge); registers beyond 2^32 work items are covered by several launches with a work-item offset
+    const uint64_t w = g.w0 + blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x;
+    if (w >= g.W) return;  // W and w0 are multiples of 64 whenever KL > 0: whole waves leave together
+    const uint64_t base = deposit(w, g);
+    amp_t x[D];
 #pragma unroll
-        for (int c = 0; c < D; ++c) x[c] = ld<NT>(a + base + hoff[c]);
-        if constexpr (KL == 0) {
+    for (int c = 0; c < D; ++c) x[c] = ld<NT>(a + base + hoff[c]);
+    if constexpr (KL == 0) {
 #pragma unroll 1
-            for (int r = 0; r < D; ++r) {
-                const double *row = M + 2 * D * r;
-                amp_t acc = {0.0, 0.0};
+        for (int r = 0; r < D; ++r) {
+            const double *row = M + 2 * D * r;
+            amp_t acc = {0.0, 0.0};
 #pragma unroll
-                for (int c = 0; c < D; ++c) acc = cfma(cplx{row[2 * c], row[2 * c + 1]}, x[c], acc);
-                st<NT>(a + base + hoff[r], acc);  // in place: every input of this group is already in registers
-            }
-        } else {
-            const int lane = threadIdx.x & 63;
-            wave_transpose<D, KL>(x, g, lane);
-            amp_t y[D];
-#pragma unroll
-            for (int r = 0; r < D; ++r) {
-                const double *row = M + 2 * D * r;
-                amp_t acc = {0.0, 0.0};
-#pragma unroll
-                for (int c = 0; c < D; ++c) acc = cfma(cplx{row[2 * c], row[2 * c + 1]}, x[c], acc);
-                y[r] = acc;
-            }
-            wave_transpose<D, KL>(y, g, lane);
-#pragma unroll
-            for (int c = 0; c < D; ++c) st<NT>(a + base + hoff[c], y[c]);
+            for (int c = 0; c < D; ++c) acc = cfma(cplx{row[2 * c], row[2 * c + 1]}, x[c], acc);
+            st<NT>(a + base + hoff[r], acc);  // in place: every input of this group is already in registers
         }
+    } else {
+        const int lane = threadIdx.x & 63;
+        wave_transpose<D, KL>(x, g, lane);
+        amp_t y[D];
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            const double *row = M + 2 * D * r;
+            amp_t acc = {0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc = cfma(cplx{row[2 * c], row[2 * c + 1]}, x[c], acc);
+            y[r] = acc;
+        }
+        wave_transpose<D, KL>(y, g, lane);
+#pragma unroll
+        for (int c = 0; c < D; ++c) st<NT>(a + base + hoff[c], y[c]);
     }
 }
 
@@ -850,17 +851,20 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     std::sort(ins.begin(), ins.end());
     g.nins = static_cast<int>(ins.size());
     for (size_t j = 0; j < ins.size(); ++j) g.pos[j] = static_cast<uint8_t>(ins[j]);
-    const dim3 gd(grid_for(g.W, QSV_BLOCK, 0));
     // partial-line nontemporal accesses are slow: use them only when every access is a full 1 KiB per wave
     bool coalesced = true;
     for (int b : ins) coalesced = coalesced && b >= QSV_LANE_BITS;
     const bool nt = st->nontemporal != 0 && coalesced;
     snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_big<%d, %d, %s>", k, KL, nt ? "true" : "false");
-    switch (k) {
-        case 3: return dispatch_big<3>(st, KL, nt, gd, g, dev_off);
-        case 4: return dispatch_big<4>(st, KL, nt, gd, g, dev_off);
-        default: return dispatch_big<5>(st, KL, nt, gd, g, dev_off);
+    const uint64_t per_launch = 0x00ffffffull * QSV_BLOCK;  // an AQL dispatch counts work-items in 32 bits
+    for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
+        const dim3 gd(grid_for(std::min(per_launch, g.W - g.w0), QSV_BLOCK, 0));
+        const int rc2 = k == 3 ? dispatch_big<3>(st, KL, nt, gd, g, dev_off)
+                      : k == 4 ? dispatch_big<4>(st, KL, nt, gd, g, dev_off)
+                               : dispatch_big<5>(st, KL, nt, gd, g, dev_off);
+        if (rc2) return rc2;
     }
+    return QSV_OK;
 }
 
 int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user) {
