@@ -169,6 +169,21 @@ def main():
     assert out.num_qubits == n - 2
     check("measurement", out.to_numpy(), want)
 
+    # 3b. BASELINE config 5 in small: Grover search on the sharded register, success probability vs the analytic value
+    marked = (0b1011001110 >> max(0, 10 - n)) | 1
+    start = np.zeros(1 << n, dtype=complex)
+    start[0] = 1
+    st = make_state(n, start, args.backend, device)
+    for q in range(n):
+        G.H(q).apply(st)
+    iterations = 3
+    for _ in range(iterations):
+        W.grover_iteration(st, n, marked)
+    p = float(st.probabilities([marked])[0])
+    want_p = W.grover_success_probability(n, iterations)
+    assert abs(p - want_p) < 1e-12, (p, want_p)
+    assert abs(st.norm2() - 1.0) < 1e-12
+
     # 4. counter-based fill: the sharded register equals the unsharded one
     if args.backend == "gloo":
         import oracle_engine
