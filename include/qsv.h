@@ -130,6 +130,13 @@ int qsv_norm2(qsv_state *st, double *out);
 int qsv_probabilities(qsv_state *st, const uint64_t *indices, int count, double *out);
 /* <a|b> with a conjugated: the ket-ket branch of npq.fidelity (numpy_quantum.py:151-152). */
 int qsv_inner(qsv_state *a, qsv_state *b, double *re, double *im);
+/* <psi| P |psi> for the Pauli string P = paulis[0] on qubits[0] (x) paulis[1] on qubits[1] ... ('I','X','Y','Z'):
+ * npq.expect (numpy_quantum.py:194-201) for tensor products of npq.PAULIS without building the 2^N operator. */
+int qsv_expect_pauli(qsv_state *st, int k, const int *qubits, const char *paulis, double *re, double *im);
+/* Draw `shots` computational-basis outcomes from |amp|^2 by inverse-CDF sampling: out[s] is the smallest basis
+ * index whose cumulative probability exceeds u[s] * norm^2 (u[s] in [0, 1), drawn by the caller).  The register
+ * is not collapsed.  Equivalent to measuring every qubit with MZ (gates.py:188-190) on independent copies. */
+int qsv_sample(qsv_state *st, int shots, const double *u, uint64_t *out);
 
 /* ---- d-level mode registers: the "d x d (d^2 x d^2) operator along mode axes" contraction of
  *      cv_simulator (np.tensordot at simulators/cv_simulator/utils.py:15,37; gates.py:73,160) --- */

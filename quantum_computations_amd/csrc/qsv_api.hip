@@ -567,6 +567,35 @@ int qsv_probabilities(qsv_state *st, const uint64_t *indices, int count, double 
     return qsvk_probabilities(st, indices, count, out);
 }
 
+int qsv_expect_pauli(qsv_state *st, int k, const int *qubits, const char *paulis, double *re, double *im) {
+    if (!valid(st) || !re || !im || (k > 0 && (!qubits || !paulis))) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (k < 0 || k > 64) return qsv_fail(QSV_EINVAL, "bad Pauli string length");
+    int rc = check_qubits(st, k, qubits);
+    if (rc) return rc;
+    uint64_t xmask = 0, zmask = 0;
+    int n_y = 0;
+    for (int j = 0; j < k; ++j) {
+        const uint64_t bit = 1ull << bit_of(st, qubits[j]);
+        switch (paulis[j]) {
+            case 'I': case 'i': break;
+            case 'X': case 'x': xmask |= bit; break;
+            case 'Z': case 'z': zmask |= bit; break;
+            case 'Y': case 'y': xmask |= bit; zmask |= bit; ++n_y; break;
+            default: return qsv_fail(QSV_EINVAL, "Pauli letters must be I, X, Y or Z");
+        }
+    }
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvk_expect_pauli(st, xmask, zmask, n_y, re, im);
+}
+
+int qsv_sample(qsv_state *st, int shots, const double *u, uint64_t *out) {
+    if (!valid(st) || (shots > 0 && (!u || !out))) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (shots < 0 || shots > (1 << 24)) return qsv_fail(QSV_EINVAL, "shots must be in 0..2^24");
+    if (shots == 0) return QSV_OK;
+    QSV_HIP(hipSetDevice(st->device));
+    return qsvk_sample(st, shots, u, out);
+}
+
 int qsv_inner(qsv_state *a, qsv_state *b, double *re, double *im) {
     if (!valid(a) || !valid(b) || !re || !im) return qsv_fail(QSV_EINVAL, "null pointer");
     if (a->amps != b->amps) return qsv_fail(QSV_EINVAL, "registers of different sizes");

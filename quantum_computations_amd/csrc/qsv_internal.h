@@ -104,6 +104,8 @@ int qsvk_permute(qsv_state *st, const int *src_bit_of_dst_bit);
 int qsvk_norm2(qsv_state *st, double *out);
 int qsvk_inner(qsv_state *a, qsv_state *b, double *re, double *im);
 int qsvk_probabilities(qsv_state *st, const uint64_t *indices, int count, double *out);
+int qsvk_expect_pauli(qsv_state *st, uint64_t xmask, uint64_t zmask, int n_y, double *re, double *im);
+int qsvk_sample(qsv_state *st, int shots, const double *u, uint64_t *out);
 int qsvk_fill_random(qsv_state *st, uint64_t seed, uint64_t index_offset, double *norm2);
 int qsvk_scale(qsv_state *st, double re, double im);
 int qsvk_set_basis(qsv_state *st, uint64_t index);

@@ -479,6 +479,98 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_inner(const amp_t *__restrict__ a
     }
 }
 
+// <psi| P |psi> for a Pauli string: P|i> = i^{nY} (-1)^{popcount(i & zmask)} |i ^ xmask>  (Y = i X Z).
+// partials[2b], [2b+1] = real and imaginary part of this block's share of sum_i conj(psi[i ^ xmask]) sign(i) psi[i];
+// the factor i^{nY} is applied on the host.
+__global__ __launch_bounds__(QSV_BLOCK) void k_expect_pauli(const amp_t *__restrict__ a, uint64_t amps,
+                                                           uint64_t xmask, uint64_t zmask,
+                                                           double *__restrict__ partials) {
+    double re = 0.0, im = 0.0;
+    for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < amps;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const amp_t x = a[i ^ xmask], y = a[i];
+        const double s = (__popcll(i & zmask) & 1) ? -1.0 : 1.0;
+        re += s * (x.x * y.x + x.y * y.y);  // conj(x) * y
+        im += s * (x.x * y.y - x.y * y.x);
+    }
+    block_sum2(re, im);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = re;
+        partials[2 * blockIdx.x + 1] = im;
+    }
+}
+
+// Sampling, pass 1: chunk_sums[c] = sum of |amp|^2 over chunk c (SAMPLE_CHUNK consecutive amplitudes per workgroup).
+constexpr int SAMPLE_CHUNK = 4096;
+
+__global__ __launch_bounds__(QSV_BLOCK) void k_chunk_sums(const amp_t *__restrict__ a, uint64_t amps,
+                                                         double *__restrict__ chunk_sums) {
+    const uint64_t chunks = (amps + SAMPLE_CHUNK - 1) / SAMPLE_CHUNK;
+    for (uint64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        double s = 0.0, unused = 0.0;
+        // thread t owns SAMPLE_CHUNK / QSV_BLOCK consecutive amplitudes: the same split pass 2 walks
+        constexpr int PER = SAMPLE_CHUNK / QSV_BLOCK;
+        const uint64_t first = c * SAMPLE_CHUNK + static_cast<uint64_t>(threadIdx.x) * PER;
+        for (int k = 0; k < PER; ++k)
+            if (first + k < amps) {
+                const amp_t v = a[first + k];
+                s += v.x * v.x + v.y * v.y;
+            }
+        __syncthreads();  // block_sum2 reuses its shared scratch across iterations
+        block_sum2(s, unused);
+        if (threadIdx.x == 0) chunk_sums[c] = s;
+    }
+}
+
+// Sampling, pass 2: one workgroup per shot walks its chunk and returns the first index whose running sum of
+// |amp|^2 exceeds `residual` (clamped to the chunk's last amplitude against rounding).
+__global__ __launch_bounds__(QSV_BLOCK) void k_sample_in_chunk(const amp_t *__restrict__ a, uint64_t amps,
+                                                              const uint64_t *__restrict__ chunk_of_shot,
+                                                              const double *__restrict__ residual_of_shot,
+                                                              uint64_t *__restrict__ out) {
+    __shared__ double part[QSV_BLOCK];
+    constexpr int PER = SAMPLE_CHUNK / QSV_BLOCK;
+    const uint64_t c = chunk_of_shot[blockIdx.x];
+    const double residual = residual_of_shot[blockIdx.x];
+    const uint64_t first = c * SAMPLE_CHUNK + static_cast<uint64_t>(threadIdx.x) * PER;
+    double mine[PER];
+    double s = 0.0;
+    for (int k = 0; k < PER; ++k) {
+        double p = 0.0;
+        if (first + k < amps) {
+            const amp_t v = a[first + k];
+            p = v.x * v.x + v.y * v.y;
+        }
+        mine[k] = p;
+        s += p;
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = 0.0;
+        int t = 0;
+        for (; t < QSV_BLOCK - 1; ++t) {
+            if (run + part[t] > residual) break;
+            run += part[t];
+        }
+        part[0] = run;                       // sum before thread t
+        part[1] = static_cast<double>(t);    // the thread that holds the crossing
+    }
+    __syncthreads();
+    const int owner = static_cast<int>(part[1]);
+    if (threadIdx.x == owner) {
+        double run = part[0];
+        int k = 0;
+        for (; k < PER - 1; ++k) {
+            if (run + mine[k] > residual) break;
+            run += mine[k];
+        }
+        uint64_t idx = first + k;
+        if (idx >= amps) idx = amps - 1;
+        out[blockIdx.x] = idx;
+    }
+}
+
 __global__ void k_gather_prob(const amp_t *__restrict__ a, const uint64_t *__restrict__ idx, int count,
                               double *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1106,6 +1198,69 @@ int qsvk_inner(qsv_state *a, qsv_state *b, double *re, double *im) {
     int rc = check_launch();
     if (rc) return rc;
     return sum_partials(a, grid, re, im);
+}
+
+int qsvk_expect_pauli(qsv_state *st, uint64_t xmask, uint64_t zmask, int n_y, double *re, double *im) {
+    const int grid = grid_for(st->amps, QSV_BLOCK * 8, QSV_REDUCE_BLOCKS);
+    hipLaunchKernelGGL(k_expect_pauli, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, xmask, zmask,
+                       st->partials);
+    int rc = check_launch();
+    if (rc) return rc;
+    double sr = 0.0, si = 0.0;
+    rc = sum_partials(st, grid, &sr, &si);
+    if (rc) return rc;
+    switch (n_y & 3) {  // times i^{nY}
+        case 0: *re = sr; *im = si; break;
+        case 1: *re = -si; *im = sr; break;
+        case 2: *re = -sr; *im = -si; break;
+        default: *re = si; *im = -sr; break;
+    }
+    return QSV_OK;
+}
+
+// Inverse-CDF sampling of basis states: out[s] = smallest index i with sum_{j <= i} |amp_j|^2 > u[s] * total.
+int qsvk_sample(qsv_state *st, int shots, const double *u, uint64_t *out) {
+    const uint64_t chunks = (st->amps + SAMPLE_CHUNK - 1) / SAMPLE_CHUNK;
+    const size_t sums_bytes = sizeof(double) * chunks, shot_bytes = sizeof(uint64_t) * shots;
+    int rc = qsvk_ensure_matrix(st, sums_bytes + 3 * shot_bytes + 64);
+    if (rc) return rc;
+    char *base = reinterpret_cast<char *>(st->dev_matrix);
+    double *d_sums = reinterpret_cast<double *>(base);
+    uint64_t *d_chunk = reinterpret_cast<uint64_t *>(base + (sums_bytes + 15) / 16 * 16);
+    double *d_resid = reinterpret_cast<double *>(d_chunk + shots);
+    uint64_t *d_out = reinterpret_cast<uint64_t *>(d_resid + shots);
+    hipLaunchKernelGGL(k_chunk_sums, dim3(grid_for(chunks, 1, 1 << 16)), dim3(QSV_BLOCK), 0, st->stream, st->data,
+                       st->amps, d_sums);
+    rc = check_launch();
+    if (rc) return rc;
+    std::vector<double> sums(chunks);
+    QSV_HIP(hipMemcpyAsync(sums.data(), d_sums, sums_bytes, hipMemcpyDeviceToHost, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));
+    std::vector<double> cum(chunks + 1, 0.0);
+    for (uint64_t c = 0; c < chunks; ++c) cum[c + 1] = cum[c] + sums[c];
+    const double total = cum[chunks];
+    if (!(total > 0.0)) return qsv_fail(QSV_EINVAL, "cannot sample from a register of zero norm");
+    std::vector<uint64_t> chunk(shots);
+    std::vector<double> resid(shots);
+    for (int s = 0; s < shots; ++s) {
+        if (!(u[s] >= 0.0 && u[s] < 1.0)) return qsv_fail(QSV_EINVAL, "uniform draws must lie in [0, 1)");
+        const double target = u[s] * total;
+        uint64_t c = std::upper_bound(cum.begin(), cum.end(), target) - cum.begin();  // first cum > target
+        c = c == 0 ? 0 : c - 1;
+        while (c + 1 < chunks && sums[c] == 0.0) ++c;  // never land in an empty chunk
+        if (c >= chunks) c = chunks - 1;
+        chunk[s] = c;
+        resid[s] = target - cum[c];
+    }
+    QSV_HIP(hipMemcpyAsync(d_chunk, chunk.data(), shot_bytes, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipMemcpyAsync(d_resid, resid.data(), sizeof(double) * shots, hipMemcpyHostToDevice, st->stream));
+    hipLaunchKernelGGL(k_sample_in_chunk, dim3(shots), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, d_chunk,
+                       d_resid, d_out);
+    rc = check_launch();
+    if (rc) return rc;
+    QSV_HIP(hipMemcpyAsync(out, d_out, shot_bytes, hipMemcpyDeviceToHost, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));  // also covers the two pageable uploads above
+    return QSV_OK;
 }
 
 int qsvk_probabilities(qsv_state *st, const uint64_t *indices, int count, double *out) {

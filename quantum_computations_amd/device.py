@@ -36,9 +36,10 @@ def _ints(values) -> "C.Array[C.c_int]":
 class DeviceState:
     """An n-qubit complex128 register in HBM (qubit 0 = most significant bit, as in the reference)."""
 
-    def __init__(self, handle: C.c_void_p, keepalive=None):
+    def __init__(self, handle: C.c_void_p, keepalive=None, device: int = 0):
         self._h = handle
         self._keepalive = keepalive   # e.g. the torch tensor backing a view
+        self.device = device          # HIP device ordinal the register lives on
 
     # ---- construction -------------------------------------------------------------------------
     @classmethod
@@ -46,7 +47,7 @@ class DeviceState:
         """|0...0> on ``device`` (``n_qubits = 0`` is the empty register ``[1.]``, simulator.py:22)."""
         h = C.c_void_p()
         _lib.call("qsv_create", int(n_qubits), int(device), C.byref(h))
-        return cls(h)
+        return cls(h, device=int(device))
 
     @classmethod
     def from_numpy(cls, ket: np.ndarray, device: int = 0) -> "DeviceState":
@@ -68,7 +69,7 @@ class DeviceState:
         h = C.c_void_p()
         _lib.call("qsv_create_view", int(n_qubits), int(device), C.c_void_p(dev_ptr), int(capacity_amps),
                   C.c_void_p(stream), C.byref(h))
-        return cls(h, keepalive)
+        return cls(h, keepalive, int(device))
 
     @classmethod
     def random(cls, n_qubits: int, seed: int, device: int = 0) -> "DeviceState":
@@ -136,7 +137,7 @@ class DeviceState:
         _lib.call("qsv_upload", self._h, _ptr(buf), int(offset), buf.size)
 
     def copy(self) -> "DeviceState":
-        other = DeviceState.zeros(self.num_qubits)
+        other = DeviceState.zeros(self.num_qubits, self.device)
         _lib.call("qsv_copy", other._h, self._h)
         return other
 
@@ -242,6 +243,23 @@ class DeviceState:
         out = np.empty(idx.size, dtype=np.float64)
         _lib.call("qsv_probabilities", self._h, idx.ctypes.data_as(C.POINTER(C.c_uint64)), idx.size,
                   out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def expect_pauli(self, paulis: str, qubits) -> complex:
+        """``<psi| P |psi>`` for the Pauli string ``paulis`` (letters I/X/Y/Z) on ``qubits``, computed on the device."""
+        qubits = [int(q) for q in qubits]
+        if len(paulis) != len(qubits):
+            raise ValueError("one Pauli letter per qubit")
+        re, im = C.c_double(), C.c_double()
+        _lib.call("qsv_expect_pauli", self._h, len(qubits), _ints(qubits), paulis.encode(), C.byref(re), C.byref(im))
+        return complex(re.value, im.value)
+
+    def sample(self, shots: int, rng=None) -> np.ndarray:
+        """``shots`` computational-basis outcomes drawn from |amplitude|^2 (inverse-CDF on the device; the uniforms
+        come from ``rng``, a ``numpy.random.Generator``, default the global ``np.random`` state).  No collapse."""
+        u = np.ascontiguousarray(rng.random(shots) if rng is not None else np.random.random_sample(shots))
+        out = np.empty(shots, dtype=np.uint64)
+        _lib.call("qsv_sample", self._h, int(shots), _ptr(u), out.ctypes.data_as(C.c_void_p))
         return out
 
     def inner(self, other: "DeviceState") -> complex:

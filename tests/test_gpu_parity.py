@@ -311,6 +311,52 @@ def test_readout_helpers():
     assert np.array_equal(dev.download(16, 32), dev.to_numpy()[16:48])
 
 
+@pytest.mark.parametrize("n", [3, 7, 13])
+def test_pauli_expectations_and_sampling(n):
+    """Device-side read-out: <psi|P|psi> against the dense Pauli operator built from npq.PAULIS (the reference's
+    npq.expect on a Kronecker product), and inverse-CDF sampling against the host cumulative distribution."""
+    from quantum_computations_amd.dv_simulator import numpy_quantum as npq
+    rng = np.random.default_rng(n)
+    ket = W.random_ket(n, 60 + n)
+    dev = DeviceState.from_numpy(ket)
+    mats = {"I": npq.IDTY, "X": npq.X, "Y": npq.Y, "Z": npq.Z}
+    for trial in range(12):
+        k = int(rng.integers(1, min(n, 5) + 1))
+        qubits = [int(q) for q in rng.choice(n, size=k, replace=False)]
+        letters = "".join(rng.choice(list("IXYZ"), size=k))
+        got = dev.expect_pauli(letters, qubits)
+        phi = ket
+        for letter, q in zip(letters, qubits):
+            phi = O.apply_gate(phi, mats[letter], [q])
+        want = np.vdot(ket, phi)
+        assert abs(got - want) < 1e-13, (letters, qubits)
+        assert abs(got.imag) < 1e-13                     # Pauli strings are hermitian
+    with pytest.raises(ValueError):
+        dev.expect_pauli("Q", [0])
+    # sampling: identical uniforms -> identical outcomes as the host inverse CDF (away from rounding ties)
+    probs = np.abs(ket) ** 2
+    cdf = np.cumsum(probs)
+    u = rng.random(2000)
+    want_idx = np.searchsorted(cdf, u * cdf[-1], side="right")
+    margin = np.minimum(np.abs(cdf[np.minimum(want_idx, len(cdf) - 1)] - u * cdf[-1]),
+                        np.abs(np.concatenate([[0.0], cdf])[want_idx] - u * cdf[-1]))
+    got_idx = dev.sample(len(u), rng=np.random.default_rng(0))           # API shape
+    assert got_idx.dtype == np.uint64 and got_idx.max() < (1 << n)
+    import ctypes as C
+    out = np.empty(len(u), dtype=np.uint64)
+    _lib.call("qsv_sample", dev._h, len(u), u.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    safe = margin > 1e-12
+    assert safe.sum() > 1900 and np.array_equal(out[safe], want_idx[safe].astype(np.uint64))
+    # statistics: many shots reproduce the distribution of a small register
+    if n == 3:
+        shots = dev.sample(200000, rng=np.random.default_rng(5))
+        freq = np.bincount(shots.astype(np.int64), minlength=8) / 200000
+        assert np.max(np.abs(freq - probs)) < 5e-3
+    # a basis state is sampled with certainty
+    dev.set_basis((1 << n) - 2)
+    assert np.all(dev.sample(50, rng=np.random.default_rng(1)) == (1 << n) - 2)
+
+
 def _splitmix64(x):
     x = (x + np.uint64(0x9E3779B97F4A7C15))
     x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
