@@ -244,7 +244,7 @@ def main():
         from quantum_computations_amd.fusion import fuse_circuit, fusion_stats
         result["with_gate_fusion"] = {}
         for k in (3, 4, 5):
-            fused = fuse_circuit(gates, k)
+            fused = fuse_circuit(gates, k, n_qubits=n)
             for g in fused:
                 g.apply(dev)
             dev.sync()

@@ -60,12 +60,22 @@ class _Block:
         return fused
 
 
-def fuse_circuit(circuit: list, max_qubits: int = 4) -> list:
-    """Return an equivalent circuit in which runs of plain gates are merged into blocks of <= ``max_qubits`` qubits."""
+def fuse_circuit(circuit: list, max_qubits: int = 4, n_qubits: int | None = None) -> list:
+    """Return an equivalent circuit in which runs of plain gates are merged into blocks of <= ``max_qubits`` qubits.
+
+    ``n_qubits`` (the register size) makes the scheduler cost-aware: a 5-qubit block whose qubits include more than one
+    of the six least significant ones runs on the transposed variants of ``k_dense_big<5>`` at one wave per SIMD
+    (2.1-3.8 TB/s instead of ~5), so such unions are capped at 4 qubits (1.5-1.7 ms whatever the placement)."""
     if max_qubits < 2:
         return list(circuit)
     out: list = []
     open_blocks: list[_Block] = []
+
+    def allowed(union) -> bool:
+        if len(union) <= min(max_qubits, 4) or n_qubits is None:
+            return len(union) <= max_qubits
+        low = sum(1 for q in union if n_qubits - 1 - q < 6)      # qubits that are lane bits of the kernels
+        return len(union) <= max_qubits and low <= 1
 
     def flush(blocks):
         for b in blocks:
@@ -81,7 +91,7 @@ def fuse_circuit(circuit: list, max_qubits: int = 4) -> list:
             continue
         touched = [b for b in open_blocks if set(b.qubits) & set(gate.indices)]
         union = set(gate.indices).union(*(b.qubits for b in touched))
-        if touched and len(union) <= max_qubits:
+        if touched and allowed(union):
             first = touched[0]
             for other in touched[1:]:
                 first.merge(other)
