@@ -296,6 +296,7 @@ struct BigArgs {
     uint8_t pos[2 * QSV_MAX_K];  // ascending: high targets and stand-in bits
     uint64_t or_mask;            // unused (0); lets deposit() serve this struct too
     uint64_t w0;                 // first work item of this launch (registers beyond 2^32 work items take several)
+    uint32_t regions;            // tile order (see GateArgs::remap)
     int32_t lbit[QSV_MAX_K];     // lane-bit position of low target j (register index bit j)
 };
 
@@ -323,7 +324,11 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_dense_big(amp_t *__restrict__ a, 
     constexpr int D = 1 << K;
     // straight-line body (a grid-stride loop here cost the k = 5 transposed variants 4x: registers live across
     // the back edge); registers beyond 2^32 work items are covered by several launches with a work-item offset
-    const uint64_t w = g.w0 + blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x;
+    // tile order as in k_dense: `regions` contiguous pieces of this launch's range walked side by side
+    const uint64_t tile = (g.regions > 1 && gridDim.x % g.regions == 0)
+                              ? (blockIdx.x % g.regions) * (gridDim.x / g.regions) + blockIdx.x / g.regions
+                              : blockIdx.x;
+    const uint64_t w = g.w0 + tile * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x;
     if (w >= g.W) return;  // W and w0 are multiples of 64 whenever KL > 0: whole waves leave together
     const uint64_t base = deposit(w, g);
     amp_t x[D];
@@ -948,6 +953,7 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     for (int b : ins) coalesced = coalesced && b >= QSV_LANE_BITS;
     const bool nt = st->nontemporal != 0 && coalesced;
     snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_big<%d, %d, %s>", k, KL, nt ? "true" : "false");
+    g.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : 8;
     const uint64_t per_launch = 0x00ffffffull * QSV_BLOCK;  // an AQL dispatch counts work-items in 32 bits
     for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
         const dim3 gd(grid_for(std::min(per_launch, g.W - g.w0), QSV_BLOCK, 0));
