@@ -170,6 +170,11 @@ int qsv_mode_insert(qsv_state *st, int mode, const double *vec /* d */);
  * tensordot+moveaxis of whittaker_shannon / rotation (cv_simulator/utils.py:9-39) on an MPS site. */
 int qsv_tensor_apply_axis(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L,
                           uint64_t d_in, uint64_t d_out, uint64_t R, const double *m /* d_out x d_in */);
+/* Same with the operator already in device memory (the reference's gates build their d x d matrix once in
+ * __init__, cv_simulator/gates.py:48-52,61-66, and reuse it for every apply): nothing is uploaded and the call
+ * is asynchronous on `hip_stream`.  Grids of >= 64 points go to rocBLAS zgemm when it can be loaded. */
+int qsv_tensor_apply_axis_dev(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L,
+                              uint64_t d_in, uint64_t d_out, uint64_t R, const void *dev_m /* d_out x d_in */);
 
 /* ---- timing on the state's stream (HIP events), for bench.py's roofline figures ----------- */
 int qsv_timer_start(qsv_state *st);

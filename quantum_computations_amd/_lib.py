@@ -68,6 +68,8 @@ SIGNATURES: dict[str, list] = {
     "qsv_mode_insert": [_state_p, C.c_int, C.c_void_p],
     "qsv_tensor_apply_axis": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                               C.c_uint64, C.c_void_p],
+    "qsv_tensor_apply_axis_dev": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                              C.c_uint64, C.c_void_p],
     "qsv_timer_start": [_state_p],
     "qsv_timer_stop": [_state_p, C.POINTER(C.c_float)],
     "qsv_last_kernel": [_state_p, C.c_char_p, C.c_size_t],

@@ -11,7 +11,7 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_ROOT = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libqsv.so"
-SOURCES = ["qsv_api.hip", "qsv_kernels.hip", "qsv_qudit.hip"]
+SOURCES = ["qsv_api.hip", "qsv_kernels.hip", "qsv_qudit.hip", "qsv_gemm.hip"]
 HEADERS = [CSRC / "qsv_internal.h", REPO_ROOT / "include" / "qsv.h"]
 ARCH = "gfx950"
 
@@ -47,7 +47,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
             subprocess.run(cmd, check=True)
         objs.append(obj)
     if force or _stale(LIB_PATH, objs):
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB_PATH), *map(str, objs)]
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB_PATH), *map(str, objs), "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

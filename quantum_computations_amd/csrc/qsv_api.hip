@@ -741,6 +741,15 @@ int qsv_tensor_apply_axis(int device, void *hip_stream, const void *dev_in, void
                             static_cast<amp_t *>(dev_out), L, d_in, d_out, R, m);
 }
 
+int qsv_tensor_apply_axis_dev(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L,
+                              uint64_t d_in, uint64_t d_out, uint64_t R, const void *dev_m) {
+    if (!dev_in || !dev_out || !dev_m) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (dev_in == dev_out) return qsv_fail(QSV_EINVAL, "in-place contraction is not supported: pass distinct buffers");
+    if (L == 0 || d_in == 0 || d_out == 0 || R == 0) return qsv_fail(QSV_EINVAL, "empty tensor");
+    return qsvq_tensor_axis_dev(device, static_cast<hipStream_t>(hip_stream), static_cast<const amp_t *>(dev_in),
+                                static_cast<amp_t *>(dev_out), L, d_in, d_out, R, static_cast<const double *>(dev_m));
+}
+
 // ---- timing -----------------------------------------------------------------------------------------
 
 int qsv_timer_start(qsv_state *st) {

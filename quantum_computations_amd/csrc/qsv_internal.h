@@ -121,5 +121,10 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
 int qsvq_mode_marginal(qsv_state *st, int mode, double *probs);
 int qsvq_mode_project(qsv_state *st, int mode, int level, double scale);
 int qsvq_mode_insert(qsv_state *st, int mode, const double *vec);
+// qsv_gemm.hip: 1 = done by rocBLAS, 0 = unavailable (use the HIP kernels), < 0 = error
+int qsvg_axis_gemm(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in,
+                   uint64_t d_out, uint64_t R, const double *dev_m);
+int qsvq_tensor_axis_dev(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in,
+                         uint64_t d_out, uint64_t R, const double *dev_m);
 int qsvq_tensor_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in,
                      uint64_t d_out, uint64_t R, const double *m_host);

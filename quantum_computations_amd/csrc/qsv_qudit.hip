@@ -266,8 +266,13 @@ int grid_of(uint64_t items, int per_block, int cap) {
     return static_cast<int>(b);
 }
 
-int launch_axis(hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in, uint64_t d_out,
-                uint64_t R, const double *dev_m) {
+int launch_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in,
+                uint64_t d_out, uint64_t R, const double *dev_m) {
+    // grids of >= 64 points with enough work to fill the chip are plain GEMMs: rocBLAS (f64 MFMA), qsv_gemm.hip
+    if (d_in >= 64 && d_out >= 64 && 8.0 * L * d_in * d_out * R >= 2e8) {
+        const int rc = qsvg_axis_gemm(device, stream, in, out, L, d_in, d_out, R, dev_m);
+        if (rc != 0) return rc < 0 ? rc : QSV_OK;
+    }
     const size_t lds = sizeof(amp_t) * d_in * TR;
     if (R >= TR && lds <= 160 * 1024 - 256) {
         const uint64_t r_tiles = (R + TR - 1) / TR;
@@ -325,7 +330,7 @@ int qsvq_mode1(qsv_state *st, int mode, const double *m, bool diag) {
     amp_t *fresh = nullptr;
     rc = qsvk_scratch(st, st->amps, &fresh);
     if (rc) return rc;
-    rc = launch_axis(st->stream, st->data, fresh, L, d, d, R, st->dev_matrix);
+    rc = launch_axis(st->device, st->stream, st->data, fresh, L, d, d, R, st->dev_matrix);
     if (rc) return rc;
     return adopt(st, fresh);
 }
@@ -532,6 +537,12 @@ int qsvq_mode_insert(qsv_state *st, int mode, const double *vec) {
     return adopt_resized(st, fresh, out_amps);
 }
 
+int qsvq_tensor_axis_dev(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in,
+                         uint64_t d_out, uint64_t R, const double *dev_m) {
+    QSV_HIP(hipSetDevice(device));
+    return launch_axis(device, stream, in, out, L, d_in, d_out, R, dev_m);
+}
+
 int qsvq_tensor_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in,
                      uint64_t d_out, uint64_t R, const double *m_host) {
     QSV_HIP(hipSetDevice(device));
@@ -540,7 +551,7 @@ int qsvq_tensor_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out
     if (hipMalloc(reinterpret_cast<void **>(&dev_m), bytes) != hipSuccess)
         return qsv_fail(QSV_ENOMEM, "device allocation of the operator failed");
     hipError_t e = hipMemcpyAsync(dev_m, m_host, bytes, hipMemcpyHostToDevice, stream);
-    int rc = e == hipSuccess ? launch_axis(stream, in, out, L, d_in, d_out, R, dev_m)
+    int rc = e == hipSuccess ? launch_axis(device, stream, in, out, L, d_in, d_out, R, dev_m)
                              : qsv_fail(QSV_EHIP, std::string("operator upload: ") + hipGetErrorString(e));
     (void)hipStreamSynchronize(stream);
     (void)hipFree(dev_m);

@@ -427,7 +427,15 @@ class QuditState:
 
 def tensor_apply_axis(dev_in: int, dev_out: int, L: int, d_in: int, d_out: int, R: int, matrix, device: int = 0,
                       stream: int = 0) -> None:
-    """``out[l, :, r] = M @ in[l, :, r]`` on raw device tensors (an MPS site: L = chi_l, R = chi_r)."""
+    """``out[l, :, r] = M @ in[l, :, r]`` on raw device tensors (an MPS site: L = chi_l, R = chi_r).
+
+    ``matrix`` is a host array (uploaded on every call) or, to keep an operator resident the way the reference's
+    gates keep ``self.matrix``, the integer device address of a row-major complex128 ``(d_out, d_in)`` buffer
+    (e.g. ``torch_tensor.data_ptr()``): then nothing is copied and the call is asynchronous on ``stream``."""
+    if isinstance(matrix, (int, np.integer)):
+        _lib.call("qsv_tensor_apply_axis_dev", int(device), C.c_void_p(stream), C.c_void_p(dev_in),
+                  C.c_void_p(dev_out), int(L), int(d_in), int(d_out), int(R), C.c_void_p(int(matrix)))
+        return
     m = _cbuf(matrix, d_in * d_out)
     _lib.call("qsv_tensor_apply_axis", int(device), C.c_void_p(stream), C.c_void_p(dev_in), C.c_void_p(dev_out),
               int(L), int(d_in), int(d_out), int(R), _ptr(m))

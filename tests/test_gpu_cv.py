@@ -163,7 +163,9 @@ def test_squeezing_and_phase_on_the_grid():
     assert abs(abs(overlap) - 1.0) < 1e-8 and abs(reg.norm() - 1.0) < 1e-8
 
 
-@pytest.mark.parametrize("L,d_in,d_out,R", [(3, 40, 40, 100), (1, 64, 48, 7), (5, 1000, 1000, 2), (2, 130, 130, 70)])
+@pytest.mark.parametrize("L,d_in,d_out,R", [(3, 40, 40, 100), (1, 64, 48, 7), (5, 1000, 1000, 2), (2, 130, 130, 70),
+                                          # grids large enough for the rocBLAS route (qsv_gemm.hip): R > 1, R == 1, rectangular
+                                          (20, 256, 256, 20), (4096, 128, 128, 1), (6, 200, 72, 300)])
 def test_tensor_apply_axis_on_mps_sites(L, d_in, d_out, R):
     """out[l, :, r] = M @ in[l, :, r] on a raw (chi_l, d, chi_r) site, as utils.py:15-16 does with tensordot."""
     import torch
@@ -176,6 +178,13 @@ def test_tensor_apply_axis_on_mps_sites(L, d_in, d_out, R):
     tensor_apply_axis(t_in.data_ptr(), t_out.data_ptr(), L, d_in, d_out, R, m,
                       stream=torch.cuda.current_stream().cuda_stream)
     want = CO.apply_axis(site, m, 1)
+    assert maxdiff(t_out.cpu().numpy(), want) < 1e-9 * np.sqrt(d_in)
+    # operator resident on the device (no upload, asynchronous)
+    t_m = torch.from_numpy(m).cuda()
+    t_out.zero_()
+    tensor_apply_axis(t_in.data_ptr(), t_out.data_ptr(), L, d_in, d_out, R, t_m.data_ptr(),
+                      stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
     assert maxdiff(t_out.cpu().numpy(), want) < 1e-9 * np.sqrt(d_in)
 
 
