@@ -176,6 +176,57 @@ int qsv_tensor_apply_axis(int device, void *hip_stream, const void *dev_in, void
 int qsv_tensor_apply_axis_dev(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L,
                               uint64_t d_in, uint64_t d_out, uint64_t R, const void *dev_m /* d_out x d_in */);
 
+/* ---- matrix-product-state sites (cv_simulator/mps.py:102-201) ------------------------------
+ * The reference keeps a CV register as a list of (chi_l, d, chi_r) site tensors and, for every two-mode gate,
+ * contracts two neighbours, maps the (q_left, q_right) plane and splits the result again with a truncated SVD
+ * (cv_simulator/gates.py:48-84,151-192).  These entry points are that update on raw device tensors: every pointer
+ * is device memory (row-major complex128 unless noted), every call runs on `hip_stream` of `device`; calls that
+ * return data to the host synchronise the stream.  GEMM and SVD come from rocBLAS / rocSOLVER (bound by dlopen);
+ * without them these calls return QSV_EHIP. */
+/* C (m x n) = op(A) . op(B); op: 0 = as stored, 1 = transpose, 2 = conjugate transpose; A is (m x k) or, with an
+ * op, (k x m); likewise B.  np.tensordot(m1, m2, (2, 0)) (gates.py:68) and the environment recursions of
+ * MPS.norm / partial_density_mps (mps.py:166-190). */
+int qsv_tensor_gemm(int device, void *hip_stream, int op_a, int op_b, uint64_t m, uint64_t n, uint64_t k,
+                    const void *dev_a, const void *dev_b, void *dev_c);
+/* tensor_svd (mps.py:52-97) of the (rows x cols) matrix `dev_theta` (destroyed): m1 = U[:, :r] sqrt(S[:r]) as
+ * (rows x r), m2 = sqrt(S[:r]) Vh[:r, :] as (r x cols), r chosen by the reference's rule -- drop the longest tail of
+ * singular values whose sum stays <= max(abs_err, rel_err * sum(S)), then cap at max_bond_dim (< 0 = no cap).
+ * `capacity` = the r the output buffers can hold; *rank = r; singular_values (host, min(rows, cols) doubles) may be
+ * NULL. */
+int qsv_tensor_svd_split(int device, void *hip_stream, void *dev_theta, uint64_t rows, uint64_t cols,
+                         int64_t max_bond_dim, double abs_err, double rel_err, void *dev_m1, void *dev_m2,
+                         uint64_t capacity, uint64_t *rank, double *singular_values);
+/* The same split on the reference's randomized branch (taken when max_bond_dim * 10 < min(rows, cols), mps.py:78):
+ * Halko-Martinsson-Tropp range finder with `probes` = max_bond_dim + 10 Gaussian test vectors and
+ * `power_iterations` passes (mps.py:5-50), SVD of the small projection, first max_bond_dim triplets, then the
+ * truncation rule above.  `dev_omega` holds the test matrix the reference would draw,
+ * rng.normal(size=(min(rows, cols), probes)), as complex128 in COLUMN-major order, so that a seeded run consumes
+ * the same random stream and lands on the same subspace.  `dev_theta` is not modified. */
+int qsv_tensor_rsvd_split(int device, void *hip_stream, const void *dev_theta, uint64_t rows, uint64_t cols,
+                          int64_t max_bond_dim, int probes, int power_iterations, const void *dev_omega,
+                          double abs_err, double rel_err, void *dev_m1, void *dev_m2, uint64_t capacity,
+                          uint64_t *rank, double *singular_values /* max_bond_dim doubles or NULL */);
+/* t[l, j, r] *= diag[j] in place: Z and P on a site (gates.py:223,245). */
+int qsv_tensor_scale_axis(int device, void *hip_stream, void *dev_t, uint64_t L, uint64_t d, uint64_t R,
+                          const void *dev_diag /* d */);
+/* theta[a, j, l, b] *= plane[j, l] in place: the CZ phases on a two-site tensor (gates.py:159-160). */
+int qsv_tensor_plane_diag(int device, void *hip_stream, void *dev_theta, uint64_t L, uint64_t d, uint64_t R,
+                          const void *dev_plane /* d x d */);
+/* out[a, p, b] = sum_e vals[p, e] in[a, cols[p, e], b] over the d*d plane points p: the bilinear (q1, q2)-plane
+ * resampling of BS / CX for every bond pair at once (gates.py:74-80,187-189); cols < 0 are padding. */
+int qsv_tensor_plane_gather(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d,
+                            uint64_t R, int per_point, const int32_t *dev_cols, const void *dev_vals);
+/* out[l, r] = scale * in[l, level, r]: the site after a homodyne outcome (gates.py:108). */
+int qsv_tensor_take_level(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d,
+                          uint64_t R, uint64_t level, double scale);
+/* out[l, j, r] = vec[j] * in[l, r]: np.einsum("i,ajb -> aijb") of Insert.apply (gates.py:39). */
+int qsv_tensor_insert_axis(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d,
+                           uint64_t R, const void *dev_vec /* d */);
+/* out[j] = Re sum_{l, r} z[l, j, r] conj(t[l, j, r]) (d doubles in device memory): the diagonal of the reduced
+ * density matrix once both environments are contracted into z (mps.py:188-189). */
+int qsv_tensor_axis_overlap(int device, void *hip_stream, const void *dev_z, const void *dev_t, uint64_t L, uint64_t d,
+                            uint64_t R, void *dev_out);
+
 /* ---- timing on the state's stream (HIP events), for bench.py's roofline figures ----------- */
 int qsv_timer_start(qsv_state *st);
 int qsv_timer_stop(qsv_state *st, float *elapsed_ms); /* records, synchronises the event, returns ms */

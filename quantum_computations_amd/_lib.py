@@ -70,6 +70,17 @@ SIGNATURES: dict[str, list] = {
                               C.c_uint64, C.c_void_p],
     "qsv_tensor_apply_axis_dev": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                               C.c_uint64, C.c_void_p],
+    "qsv_tensor_gemm": [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p],
+    "qsv_tensor_svd_split": [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_uint64,
+                             C.POINTER(C.c_uint64), C.c_void_p],
+    "qsv_tensor_rsvd_split": [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double,
+                              C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p],
+    "qsv_tensor_scale_axis": [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p],
+    "qsv_tensor_plane_diag": [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p],
+    "qsv_tensor_plane_gather": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p],
+    "qsv_tensor_take_level": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double],
+    "qsv_tensor_insert_axis": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p],
+    "qsv_tensor_axis_overlap": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p],
     "qsv_timer_start": [_state_p],
     "qsv_timer_stop": [_state_p, C.POINTER(C.c_float)],
     "qsv_last_kernel": [_state_p, C.c_char_p, C.c_size_t],

@@ -750,6 +750,94 @@ int qsv_tensor_apply_axis_dev(int device, void *hip_stream, const void *dev_in, 
                                 static_cast<amp_t *>(dev_out), L, d_in, d_out, R, static_cast<const double *>(dev_m));
 }
 
+// ---- matrix-product-state sites ---------------------------------------------------------------------
+
+namespace {
+inline hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
+inline const amp_t *camp(const void *p) { return static_cast<const amp_t *>(p); }
+inline amp_t *amp(void *p) { return static_cast<amp_t *>(p); }
+inline bool empty_site(uint64_t L, uint64_t d, uint64_t R) { return L == 0 || d == 0 || R == 0; }
+}  // namespace
+
+int qsv_tensor_gemm(int device, void *hip_stream, int op_a, int op_b, uint64_t m, uint64_t n, uint64_t k,
+                    const void *dev_a, const void *dev_b, void *dev_c) {
+    if (!dev_a || !dev_b || !dev_c) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (op_a < 0 || op_a > 2 || op_b < 0 || op_b > 2) return qsv_fail(QSV_EINVAL, "op must be 0, 1 or 2");
+    if (m == 0 || n == 0 || k == 0) return qsv_fail(QSV_EINVAL, "empty matrix");
+    return qsvg_gemm(device, as_stream(hip_stream), op_a, op_b, m, n, k, camp(dev_a), camp(dev_b), amp(dev_c));
+}
+
+int qsv_tensor_svd_split(int device, void *hip_stream, void *dev_theta, uint64_t rows, uint64_t cols,
+                         int64_t max_bond_dim, double abs_err, double rel_err, void *dev_m1, void *dev_m2,
+                         uint64_t capacity, uint64_t *rank, double *singular_values) {
+    if (!dev_theta || !dev_m1 || !dev_m2 || !rank) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (rows == 0 || cols == 0) return qsv_fail(QSV_EINVAL, "empty matrix");
+    return qsvg_svd_split(device, as_stream(hip_stream), amp(dev_theta), rows, cols, max_bond_dim, abs_err, rel_err,
+                          amp(dev_m1), amp(dev_m2), capacity, rank, singular_values);
+}
+
+int qsv_tensor_rsvd_split(int device, void *hip_stream, const void *dev_theta, uint64_t rows, uint64_t cols,
+                          int64_t max_bond_dim, int probes, int power_iterations, const void *dev_omega,
+                          double abs_err, double rel_err, void *dev_m1, void *dev_m2, uint64_t capacity,
+                          uint64_t *rank, double *singular_values) {
+    if (!dev_theta || !dev_omega || !dev_m1 || !dev_m2 || !rank) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (rows == 0 || cols == 0) return qsv_fail(QSV_EINVAL, "empty matrix");
+    if (max_bond_dim < 1 || probes < max_bond_dim || power_iterations < 0)
+        return qsv_fail(QSV_EINVAL, "need max_bond_dim >= 1, probes >= max_bond_dim, power_iterations >= 0");
+    return qsvg_rsvd_split(device, as_stream(hip_stream), camp(dev_theta), rows, cols, max_bond_dim, probes,
+                           power_iterations, camp(dev_omega), abs_err, rel_err, amp(dev_m1), amp(dev_m2), capacity,
+                           rank, singular_values);
+}
+
+int qsv_tensor_scale_axis(int device, void *hip_stream, void *dev_t, uint64_t L, uint64_t d, uint64_t R,
+                          const void *dev_diag) {
+    if (!dev_t || !dev_diag) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (empty_site(L, d, R)) return qsv_fail(QSV_EINVAL, "empty tensor");
+    return qsvq_tensor_scale_axis(device, as_stream(hip_stream), amp(dev_t), L, d, R,
+                                  static_cast<const double *>(dev_diag));
+}
+
+int qsv_tensor_plane_diag(int device, void *hip_stream, void *dev_theta, uint64_t L, uint64_t d, uint64_t R,
+                          const void *dev_plane) {
+    if (!dev_theta || !dev_plane) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (empty_site(L, d, R)) return qsv_fail(QSV_EINVAL, "empty tensor");
+    return qsvq_tensor_plane_diag(device, as_stream(hip_stream), amp(dev_theta), L, d, R,
+                                  static_cast<const double *>(dev_plane));
+}
+
+int qsv_tensor_plane_gather(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d,
+                            uint64_t R, int per_point, const int32_t *dev_cols, const void *dev_vals) {
+    if (!dev_in || !dev_out || !dev_cols || !dev_vals) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (dev_in == dev_out) return qsv_fail(QSV_EINVAL, "in-place resampling is not supported: pass distinct buffers");
+    if (empty_site(L, d, R) || per_point < 1) return qsv_fail(QSV_EINVAL, "empty tensor or table");
+    if (d > 46340) return qsv_fail(QSV_EINVAL, "plane indices are 32-bit: d must be <= 46340");
+    return qsvq_tensor_plane_gather(device, as_stream(hip_stream), camp(dev_in), amp(dev_out), L, d, R, per_point,
+                                    dev_cols, static_cast<const double *>(dev_vals));
+}
+
+int qsv_tensor_take_level(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d,
+                          uint64_t R, uint64_t level, double scale) {
+    if (!dev_in || !dev_out) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (empty_site(L, d, R) || level >= d) return qsv_fail(QSV_EINVAL, "level out of range");
+    return qsvq_tensor_take_level(device, as_stream(hip_stream), camp(dev_in), amp(dev_out), L, d, R, level, scale);
+}
+
+int qsv_tensor_insert_axis(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d,
+                           uint64_t R, const void *dev_vec) {
+    if (!dev_in || !dev_out || !dev_vec) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (empty_site(L, d, R)) return qsv_fail(QSV_EINVAL, "empty tensor");
+    return qsvq_tensor_insert_axis(device, as_stream(hip_stream), camp(dev_in), amp(dev_out), L, d, R,
+                                   static_cast<const double *>(dev_vec));
+}
+
+int qsv_tensor_axis_overlap(int device, void *hip_stream, const void *dev_z, const void *dev_t, uint64_t L, uint64_t d,
+                            uint64_t R, void *dev_out) {
+    if (!dev_z || !dev_t || !dev_out) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (empty_site(L, d, R)) return qsv_fail(QSV_EINVAL, "empty tensor");
+    return qsvq_tensor_axis_overlap(device, as_stream(hip_stream), camp(dev_z), camp(dev_t), L, d, R,
+                                    static_cast<double *>(dev_out));
+}
+
 // ---- timing -----------------------------------------------------------------------------------------
 
 int qsv_timer_start(qsv_state *st) {

@@ -121,6 +121,26 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
 int qsvq_mode_marginal(qsv_state *st, int mode, double *probs);
 int qsvq_mode_project(qsv_state *st, int mode, int level, double scale);
 int qsvq_mode_insert(qsv_state *st, int mode, const double *vec);
+int qsvg_gemm(int device, hipStream_t stream, int op_a, int op_b, uint64_t m, uint64_t n, uint64_t k, const amp_t *a,
+              const amp_t *b, amp_t *c);
+int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, uint64_t cols, int64_t max_bond_dim,
+                   double abs_err, double rel_err, amp_t *m1, amp_t *m2, uint64_t capacity, uint64_t *rank_out,
+                   double *s_host);
+int qsvg_rsvd_split(int device, hipStream_t stream, const amp_t *theta, uint64_t rows, uint64_t cols, int64_t k_keep,
+                    int l, int q, const amp_t *omega, double abs_err, double rel_err, amp_t *m1, amp_t *m2,
+                    uint64_t capacity, uint64_t *rank_out, double *s_host);
+int qsvq_tensor_scale_axis(int device, hipStream_t stream, amp_t *t, uint64_t L, uint64_t d, uint64_t R,
+                           const double *dev_diag);
+int qsvq_tensor_plane_diag(int device, hipStream_t stream, amp_t *t, uint64_t L, uint64_t d, uint64_t R,
+                           const double *dev_plane);
+int qsvq_tensor_plane_gather(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d,
+                             uint64_t R, int nnz, const int32_t *dev_cols, const double *dev_vals);
+int qsvq_tensor_take_level(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d,
+                           uint64_t R, uint64_t level, double scale);
+int qsvq_tensor_insert_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d,
+                            uint64_t R, const double *dev_vec);
+int qsvq_tensor_axis_overlap(int device, hipStream_t stream, const amp_t *z, const amp_t *t, uint64_t L, uint64_t d,
+                             uint64_t R, double *dev_out);
 // qsv_gemm.hip: 1 = done by rocBLAS, 0 = unavailable (use the HIP kernels), < 0 = error
 int qsvg_axis_gemm(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in,
                    uint64_t d_out, uint64_t R, const double *dev_m);

@@ -557,3 +557,91 @@ int qsvq_tensor_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out
     (void)hipFree(dev_m);
     return rc;
 }
+
+// ====================================================================================================
+// Raw-tensor entry points for matrix-product-state sites (cv_simulator/mps.py:102-201 keeps the state as a list of
+// (chi_l, d, chi_r) tensors).  Same kernels as the register path, addressed by (L, d, R) instead of through a
+// qsv_state; every operand is a device pointer and every call is asynchronous on `stream`.
+// ====================================================================================================
+namespace {
+
+// out[j] partial sums of Re( z[l, j, r] * conj(t[l, j, r]) ) over (l, r): the last step of the reduced density
+// diagonal (mps.py:188-189 restricted to i == j).
+__global__ __launch_bounds__(QSV_BLOCK) void k_axis_overlap(const amp_t *__restrict__ z, const amp_t *__restrict__ t,
+                                                           uint64_t L, int d, uint64_t R,
+                                                           double *__restrict__ out) {
+    __shared__ double red[QSV_BLOCK / 64];
+    const int j = blockIdx.x;
+    const uint64_t fibre = L * R;
+    double s = 0.0;
+    for (uint64_t f = threadIdx.x; f < fibre; f += blockDim.x) {
+        const uint64_t l = f / R, r = f % R;
+        const amp_t a = z[(l * d + j) * R + r], b = t[(l * d + j) * R + r];
+        s += a.x * b.x + a.y * b.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double acc = 0.0;
+        for (int i = 0; i < QSV_BLOCK / 64; ++i) acc += red[i];
+        out[j] = acc;
+    }
+}
+
+}  // namespace
+
+int qsvq_tensor_scale_axis(int device, hipStream_t stream, amp_t *t, uint64_t L, uint64_t d, uint64_t R,
+                           const double *dev_diag) {
+    QSV_HIP(hipSetDevice(device));
+    const uint64_t total = L * d * R;
+    const int grid = grid_of(total, QSV_BLOCK * 4, 1 << 16);
+    hipLaunchKernelGGL(k_axis_diag, dim3(grid), dim3(QSV_BLOCK), 0, stream, t, total, static_cast<int>(d), R, dev_diag);
+    return check_launch();
+}
+
+int qsvq_tensor_plane_diag(int device, hipStream_t stream, amp_t *t, uint64_t L, uint64_t d, uint64_t R,
+                           const double *dev_plane) {
+    QSV_HIP(hipSetDevice(device));
+    const uint64_t total = L * d * d * R;
+    const int grid = grid_of(total, QSV_BLOCK * 4, 1 << 16);
+    hipLaunchKernelGGL(k_mode2_diag, dim3(grid), dim3(QSV_BLOCK), 0, stream, t, total, static_cast<int>(d),
+                       static_cast<uint64_t>(1), R, dev_plane);
+    return check_launch();
+}
+
+int qsvq_tensor_plane_gather(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d,
+                             uint64_t R, int nnz, const int32_t *dev_cols, const double *dev_vals) {
+    QSV_HIP(hipSetDevice(device));
+    const int grid = grid_of(L * d * d * R, QSV_BLOCK, 1 << 16);
+    hipLaunchKernelGGL(k_mode2_gather, dim3(grid), dim3(QSV_BLOCK), 0, stream, in, out, L, static_cast<int>(d),
+                       static_cast<uint64_t>(1), R, nnz, dev_cols, dev_vals);
+    return check_launch();
+}
+
+int qsvq_tensor_take_level(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d,
+                           uint64_t R, uint64_t level, double scale) {
+    QSV_HIP(hipSetDevice(device));
+    const int grid = grid_of(L * R, QSV_BLOCK, 1 << 16);
+    hipLaunchKernelGGL(k_mode_project, dim3(grid), dim3(QSV_BLOCK), 0, stream, in, out, L, static_cast<int>(d), R,
+                       static_cast<int>(level), scale);
+    return check_launch();
+}
+
+int qsvq_tensor_insert_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d,
+                            uint64_t R, const double *dev_vec) {
+    QSV_HIP(hipSetDevice(device));
+    const int grid = grid_of(L * d * R, QSV_BLOCK, 1 << 16);
+    hipLaunchKernelGGL(k_mode_insert, dim3(grid), dim3(QSV_BLOCK), 0, stream, in, out, L, static_cast<int>(d), R,
+                       dev_vec);
+    return check_launch();
+}
+
+int qsvq_tensor_axis_overlap(int device, hipStream_t stream, const amp_t *z, const amp_t *t, uint64_t L, uint64_t d,
+                             uint64_t R, double *dev_out) {
+    QSV_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_axis_overlap, dim3(static_cast<unsigned>(d)), dim3(QSV_BLOCK), 0, stream, z, t, L,
+                       static_cast<int>(d), R, dev_out);
+    return check_launch();
+}

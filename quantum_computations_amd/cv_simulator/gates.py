@@ -32,6 +32,23 @@ from .utils import fourier_matrix, plane_resample_table, rotation_matrix, sinc_m
 logger = logging.getLogger(__name__)
 
 
+def _truncation(gate, mps, rng=None) -> dict:
+    """Keyword arguments for the two-site split: the gate's ``svd_options`` and the simulator's generator on a site
+    register (the reference calls ``tensor_svd(..., **self.svd_options, rng_seed=rng)``), nothing on the dense one."""
+    return dict(gate.svd_options, rng_seed=rng) if mps.layout == "sites" else {}
+
+
+def _cached(gate, name: str, domain: np.ndarray, build):
+    """Host operators depend only on the gate's parameters and the grid: build once per (gate, grid) so that repeated
+    ``apply`` calls hand the register the same array object (which it keeps resident on the device)."""
+    key = (name, domain[0], domain[-1], len(domain))
+    store = gate.__dict__.setdefault("_operator_cache", {})
+    if key not in store:
+        store.clear()
+        store[key] = build()
+    return store[key]
+
+
 def _pi_fraction(angle: float) -> str:
     return f"({round(angle / np.pi, REPR_DIGITS)} * π)"
 
@@ -51,14 +68,15 @@ class _AxisGate(SingleModeGate):
         raise NotImplementedError
 
     def apply(self, mps: MPS, **_):
-        mps.reg.apply_mode(self.operator(mps.domain), self.index)
+        mps.reg.apply_mode(_cached(self, "op", mps.domain, lambda: self.operator(mps.domain)), self.index)
 
 
 class F(SingleModeGate):
     """Fourier gate: FFT on the grid followed by sinc resampling onto the same grid (``utils.fourier``)."""
 
     def apply(self, mps: MPS, **_):
-        mps.reg.apply_mode(fourier_matrix(mps.domain, inv=self.dagger), self.index)
+        mps.reg.apply_mode(_cached(self, "op", mps.domain, lambda: fourier_matrix(mps.domain, inv=self.dagger)),
+                           self.index)
 
 
 class X(_AxisGate):
@@ -135,11 +153,15 @@ class _PlaneResampling(TwoModeGate):
     def source_points(self, x: np.ndarray, y: np.ndarray):
         raise NotImplementedError
 
-    def apply(self, mps: MPS, **_):
+    def apply(self, mps: MPS, rng=None, **_):
         grid = mps.domain
-        x, y = np.meshgrid(grid, grid, indexing="ij")
-        cols, weights = plane_resample_table(grid, *self.source_points(x, y))
-        mps.reg.apply_two_mode_gather(cols, weights, self.left_index, self.right_index)
+
+        def table():
+            x, y = np.meshgrid(grid, grid, indexing="ij")
+            return plane_resample_table(grid, *self.source_points(x, y))
+
+        cols, weights = _cached(self, "table", grid, table)
+        mps.reg.apply_two_mode_gather(cols, weights, self.left_index, self.right_index, **_truncation(self, mps, rng))
 
 
 class BS(_PlaneResampling):
@@ -175,11 +197,11 @@ class CX(_PlaneResampling):
 class SWAP(TwoModeGate):
     """Exchange two neighbouring modes (a transposition of the plane)."""
 
-    def apply(self, mps: MPS, **_):
+    def apply(self, mps: MPS, rng=None, **_):
         d = len(mps.domain)
         transposed = np.arange(d * d).reshape(d, d).T.reshape(-1, 1)          # new[i, j] = old[j, i]
         mps.reg.apply_two_mode_gather(transposed, np.ones(transposed.shape, dtype=np.complex128),
-                                      self.left_index, self.right_index)
+                                      self.left_index, self.right_index, **_truncation(self, mps, rng))
 
 
 class CZ(TwoModeGate):
@@ -188,10 +210,10 @@ class CZ(TwoModeGate):
     def __init__(self, index1, index2, s: float = 1.0, **kwargs):
         super().__init__(index1, index2, arg=s, **kwargs)
 
-    def apply(self, mps: MPS, **_):
+    def apply(self, mps: MPS, rng=None, **_):
         strength = -self.arg if self.dagger else self.arg
-        mps.reg.apply_two_mode(np.exp(1j * strength * np.outer(mps.domain, mps.domain)),
-                               self.left_index, self.right_index)
+        plane = _cached(self, "plane", mps.domain, lambda: np.exp(1j * strength * np.outer(mps.domain, mps.domain)))
+        mps.reg.apply_two_mode(plane, self.left_index, self.right_index, **_truncation(self, mps, rng))
 
 
 # ---- measurements and insertion -----------------------------------------------------------------------------------
@@ -251,8 +273,8 @@ class Insert(SingleModeGate):
         super().__init__(index, arg=state, **kwargs)
         self.gkp_epsilon = gkp_epsilon
 
-    def apply(self, mps: MPS, **_):
+    def apply(self, mps: MPS, rng=None, **_):
         if not 0 <= self.index <= len(mps):
             raise IndexError(f"Cannot insert mode at index {self.index} for MPS of length {len(mps)}")
         prepared = self.arg.eval(mps.domain, self.gkp_epsilon) if hasattr(self.arg, "eval") else np.asarray(self.arg)
-        mps.reg.insert(self.index, prepared)
+        mps.reg.insert(self.index, prepared, **_truncation(self, mps, rng))

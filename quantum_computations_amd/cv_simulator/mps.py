@@ -1,12 +1,15 @@
-"""Register of the CV simulator: a DENSE position-grid wavefunction in HBM behind the reference's ``MPS`` surface.
+"""Register of the CV simulator behind the reference's ``MPS`` surface, in HBM, in one of two layouts.
 
-The reference stores the state as a matrix-product state (``simulators/cv_simulator/mps.py:102-201``) and recompresses
-with an SVD after every two-mode gate.  The tensor-network compression is out of scope for this round (SURVEY.md row 7 /
-8f-3: a dense-LAPACK problem, not the bandwidth-bound gate path); what is in scope is the gate application itself, so
-``MPS`` here keeps the constructor, ``domain`` / ``diff``, ``len``, ``copy``, ``validate``, ``contract``, ``norm`` and
-``partial_density_mps`` of the reference class but holds the *contracted* tensor ``psi[q_0, ..., q_{m-1}]`` as a
-``QuditState`` (``d = len(domain)`` levels per mode).  Results equal the reference's with truncation disabled
-(``rel_err = 0``); ``svd_options`` are accepted and ignored.  Registers are limited by ``d^m * 16`` bytes of HBM.
+``layout="dense"`` (default) holds the *contracted* tensor ``psi[q_0, ..., q_{m-1}]`` as a ``QuditState``
+(``d = len(domain)`` levels per mode): every gate is one bandwidth-bound pass, results equal the reference's with
+truncation disabled (``rel_err = 0``), truncation keywords are ignored, and the size is limited by ``d^m * 16`` bytes.
+
+``layout="sites"`` is the reference's own data structure -- a chain of ``(chi_l, d, chi_r)`` site tensors
+(``simulators/cv_simulator/mps.py:102-201``) re-compressed with a truncated SVD after every two-mode gate -- kept on the
+device by ``site_register.SiteRegister``; this is what reaches the reference's d = 1000 grids.
+
+Either way the class keeps the constructor, ``domain`` / ``diff``, ``len``, ``copy``, ``validate``, ``contract``,
+``norm`` and ``partial_density_mps`` of the reference class, and the gate classes drive both through the same calls.
 """
 from __future__ import annotations
 
@@ -19,8 +22,23 @@ from ..device import QuditState
 
 
 def tensor_svd(tensor, left_indices, right_indices, *, max_bond_dim: int = np.inf, abs_err: float = 0,
-               rel_err: float = 1e-12, rng_seed: int = None):
-    raise NotImplementedError("MPS compression (truncated SVD) is not part of the MI355X gate path yet (SURVEY.md 8f-3)")
+               rel_err: float = 1e-12, rng_seed: int = None, device: int = 0):
+    """Split a host tensor by a truncated SVD on the device (``tensor_svd``, mps.py:52-97): returns ``m1`` with legs
+    ``left_indices + [j]`` and ``m2`` with legs ``[j] + right_indices``; the singular values are shared as square
+    roots and the kept rank follows the reference's rule (tail sum <= max(abs_err, rel_err * sum), then the cap)."""
+    from .site_register import SiteRegister
+    left_indices, right_indices = list(left_indices), list(right_indices)
+    if sorted(left_indices + right_indices) != list(range(np.ndim(tensor))):
+        raise IndexError("Output indices does not match indices of initial tensor")
+    shape = np.shape(tensor)
+    rows = int(np.prod([shape[i] for i in left_indices]))
+    cols = int(np.prod([shape[i] for i in right_indices]))
+    matrix = np.moveaxis(np.asarray(tensor), left_indices + right_indices, range(len(shape))).reshape(rows, cols)
+    worker = SiteRegister([], 1, device)
+    m1, m2, r = worker._split(worker._upload(matrix), rows, cols, max_bond_dim=max_bond_dim, abs_err=abs_err,
+                              rel_err=rel_err)
+    return (m1.cpu().numpy().reshape([shape[i] for i in left_indices] + [r]),
+            m2.cpu().numpy().reshape([r] + [shape[i] for i in right_indices]))
 
 
 # the keyword-only truncation options gates and the simulator accept (mps.py:99-100)
@@ -29,16 +47,22 @@ SVD_OPTIONS = {name: p for name, p in inspect.signature(tensor_svd).parameters.i
 
 
 class MPS:
-    def __init__(self, domain: np.ndarray, tensors: list[np.ndarray], *, device: int = 0):
-        """``tensors``: one entry per mode -- a wavefunction on ``domain`` (1-D) or an MPS site ``(chi_l, d, chi_r)``;
-        sites are contracted on the host (small registers) and the dense tensor is uploaded."""
+    def __init__(self, domain: np.ndarray, tensors: list[np.ndarray], *, device: int = 0, layout: str = "dense"):
+        """``tensors``: one entry per mode -- a wavefunction on ``domain`` (1-D) or an MPS site ``(chi_l, d, chi_r)``.
+        ``layout="dense"``: the sites are contracted on the host (small registers) and the dense tensor is uploaded;
+        ``layout="sites"``: the sites are uploaded as they are and stay a matrix-product state."""
+        if layout not in ("dense", "sites"):
+            raise ValueError("layout must be 'dense' or 'sites'")
         self.domain: np.ndarray = domain
         self._check_domain()
         self.diff: float = abs(domain[-1] - domain[0]) / (len(domain) - 1)
         sites = [np.asarray(t).reshape(1, -1, 1) if np.ndim(t) == 1 else np.asarray(t) for t in tensors]
         self._check_sites(sites)
         d = len(domain)
-        if sites:
+        if layout == "sites":
+            from .site_register import SiteRegister
+            self.reg = SiteRegister(sites, d, device)
+        elif sites:
             dense = np.squeeze(reduce(lambda a, b: np.tensordot(a, b, axes=1), sites), axis=(0, -1))
             self.reg = QuditState.from_numpy(np.ascontiguousarray(dense, dtype=np.complex128).reshape((d,) * len(sites)),
                                              device)
@@ -60,7 +84,20 @@ class MPS:
     def copy(self) -> "MPS":
         return MPS._wrap(self.domain.copy(), self.reg.copy())
 
+    @property
+    def layout(self) -> str:
+        return getattr(self.reg, "layout", "dense")
+
+    @property
+    def tensors(self) -> list[np.ndarray]:
+        """Host copies of the site tensors (``layout="sites"`` only; the dense register has no sites)."""
+        if self.layout != "sites":
+            raise AttributeError("a dense register has no site tensors: build the MPS with layout='sites'")
+        return self.reg.site_arrays()
+
     def shape(self):
+        if self.layout == "sites":
+            return self.reg.shape()
         n, d = self.reg.dims
         return ("dense",) + (d,) * n
 
@@ -113,6 +150,8 @@ class MPS:
         for read-out of small registers; measurements use :meth:`marginal`, which stays on the GPU."""
         if axis < 0 or axis >= len(self):
             raise IndexError(f"axis={axis} out of bounds")
+        if self.layout == "sites":
+            return self.reg.reduced_density(axis) * self.diff ** (len(self) - 1)
         psi = np.moveaxis(self.contract(), axis, 0).reshape(len(self.domain), -1)
         return (psi @ psi.conj().T) * self.diff ** (len(self) - 1)
 

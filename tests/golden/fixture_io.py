@@ -49,3 +49,13 @@ def unpack_ops(meta_json: str, mats: np.ndarray, state_vectors: dict | None = No
             o["vector"] = state_vectors[o["state"]]
         ops.append(o)
     return ops
+
+
+def cv_mps_program(cv, State, options):
+    """The truncated-MPS golden circuit, built from a gate module (the reference's here, ours in the tests)."""
+    return [cv.Insert(0, State.VACUUM), cv.Insert(1, State.GKP_PLUS, gkp_epsilon=0.3),
+            cv.Insert(2, State.GKP_ZERO, gkp_epsilon=0.35), cv.X(0, 0.4), cv.CZ(0, 1, 0.5, **options), cv.F(2),
+            cv.BS(1, 2, 0.6, **options), cv.P(1, 0.2), cv.CX(1, 0, 0.5, **options), cv.SWAP(0, 1, **options),
+            cv.Insert(1, State.GKP_ONE, gkp_epsilon=0.3, **options), cv.CZ(2, 1, 0.4, dagger=True, **options),
+            cv.BS(3, 2, 0.3, **options), cv.Z(0, 1.1), cv.Homodyne(2, 0.4, 0.8), cv.D(0, [0.3, -0.2]),
+            cv.CX(1, 2, 0.7, **options), cv.F(1, dagger=True), cv.Mp(0, -0.5)]

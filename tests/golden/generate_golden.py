@@ -24,7 +24,7 @@ sys.path.insert(0, str(REPO))
 sys.path.insert(0, str(HERE))
 sys.path.insert(0, str(REFERENCE))
 
-from fixture_io import pack_ops  # noqa: E402
+from fixture_io import cv_mps_program, pack_ops  # noqa: E402
 from quantum_computations_amd import workloads as W  # noqa: E402
 
 # --- the reference (untrusted public code: imported to be RUN, nothing is copied) ---------------------------
@@ -397,11 +397,61 @@ def gen_cv_extra():
     save("cv_extra.npz", cases=json.dumps(cases), **arrays)
 
 
+def gen_cv_mps():
+    """Matrix-product states WITH truncation through the reference's gates: site shapes after every gate, checkpoints
+    of the contracted state, norms and measurement records.  Grid and caps are chosen so that the
+    reference stays on its exact-SVD branch (max_bond_dim * 10 >= min(matrix shape), mps.py:78)."""
+    from simulators.cv_simulator.states import State as RefCVState
+    from simulators.cv_simulator.mps import tensor_svd as ref_tensor_svd
+
+    arrays, cases = {}, []
+    d = 20
+    qs = np.linspace(-6.5, 6.5, d)
+    arrays["qs"] = qs
+    for label, options in [("rel1e-6", {"rel_err": 1e-6}), ("cap5", {"max_bond_dim": 5}),
+                           ("abs1e-3", {"abs_err": 1e-3, "rel_err": 0.0})]:
+        mps = RefMPS(qs, [])
+        rng = np.random.default_rng(5)
+        shapes, norms, results = [], [], []
+        for position, gate in enumerate(cv_mps_program(ref_cv, RefCVState, options)):
+            out = gate.apply(mps, rng=rng)
+            if out is not None and hasattr(out, "probability"):
+                results.append([position, out.result, out.probability])
+            shapes.append([list(t.shape) for t in mps.tensors])
+            norms.append(float(np.real(mps.norm())))
+            if position in (6, 9, 14, 18):
+                arrays[f"{label}_state_{position}"] = np.asarray(mps.contract(), dtype=np.complex128)
+        arrays[f"{label}_norms"] = np.array(norms)
+        arrays[f"{label}_results"] = np.array(results)
+        arrays[f"{label}_marginal"] = np.real(np.diag(mps.partial_density_mps(1)))
+        arrays[f"{label}_rho0"] = np.asarray(mps.partial_density_mps(0), dtype=np.complex128)
+        cases.append({"label": label, "options": options, "shapes": shapes})
+
+    # tensor_svd itself on random tensors (exact branch), all three truncation modes
+    rng = np.random.default_rng(23)
+    for idx, (shape, left, right, options) in enumerate([
+            ((3, 8, 8, 2), [0, 1], [2, 3], {"rel_err": 1e-3}),
+            ((4, 6, 6, 5), [0, 2], [1, 3], {"max_bond_dim": 7}),
+            ((2, 9, 9, 3), [0, 1], [2, 3], {"abs_err": 0.8, "rel_err": 0.0}),
+            ((5, 7, 7, 1), [0, 1], [2, 3], {})]):
+        t = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+        t *= np.exp(-0.4 * np.arange(shape[1]))[None, :, None, None]        # decaying spectrum so truncation bites
+        m1, m2 = ref_tensor_svd(t, left, right, **options)
+        arrays[f"svd_in_{idx}"] = t
+        arrays[f"svd_product_{idx}"] = np.tensordot(m1, m2, axes=1)
+        cases.append({"kind": "tensor_svd", "index": idx, "left": left, "right": right, "options": options,
+                      "rank": int(m1.shape[-1])})
+    save("cv_mps.npz", cases=json.dumps(cases), **arrays)
+
+
 if __name__ == "__main__":
     import logging
     logging.getLogger("simulators").setLevel(logging.ERROR)
     if "--cv-extra-only" in sys.argv:
         gen_cv_extra()
+        sys.exit(0)
+    if "--cv-mps-only" in sys.argv:
+        gen_cv_mps()
         sys.exit(0)
     gen_single_gates()
     gen_expand_gate()
@@ -410,3 +460,5 @@ if __name__ == "__main__":
     gen_measure_insert()
     gen_grover()
     gen_cv()
+    gen_cv_extra()
+    gen_cv_mps()
