@@ -216,6 +216,13 @@ int qsv_tensor_plane_diag(int device, void *hip_stream, void *dev_theta, uint64_
  * resampling of BS / CX for every bond pair at once (gates.py:74-80,187-189); cols < 0 are padding. */
 int qsv_tensor_plane_gather(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d,
                             uint64_t R, int per_point, const int32_t *dev_cols, const void *dev_vals);
+/* The same two maps with nothing tabulated: theta[a, j, l, b] *= exp(i strength q_j q_l) (CZ), and
+ * out[a, i0, i1, b] = bilinear interpolation of in[a, :, :, b] at (a00 q_i0 + a01 q_i1, a10 q_i0 + a11 q_i1), zero
+ * outside the grid (BS: a rotation; CX: a shear).  `dev_grid` = the d grid points (doubles, ascending). */
+int qsv_tensor_plane_phase(int device, void *hip_stream, void *dev_theta, uint64_t L, uint64_t d, uint64_t R,
+                           const void *dev_grid, double strength);
+int qsv_tensor_plane_affine(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d,
+                            uint64_t R, const void *dev_grid, const double *a /* a00 a01 a10 a11, host */);
 /* out[l, r] = scale * in[l, level, r]: the site after a homodyne outcome (gates.py:108). */
 int qsv_tensor_take_level(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d,
                           uint64_t R, uint64_t level, double scale);

@@ -1,0 +1,162 @@
+"""TEST INFRASTRUCTURE ONLY — NumPy restatement of the reference's matrix-product-state update (cv_simulator).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the CPU-baseline legs of the benchmarks may import this module; the
+product (``quantum_computations_amd``) never does.
+
+What is restated, with the reference lines each piece follows:
+
+* ``range_finder`` / ``randomized_svd`` -- ``simulators/cv_simulator/mps.py:5-50`` (Halko-Martinsson-Tropp range finder,
+  fixed oversampling 10, 7 or 4 power iterations, SVD of the projected matrix);
+* ``split`` -- ``tensor_svd``, ``mps.py:52-97`` (exact LAPACK SVD unless ``max_bond_dim * 10 < min(shape)``, the
+  tail-sum truncation rule, square roots of the singular values shared between the factors);
+* ``Chain`` -- the ``MPS`` container (``mps.py:102-201``: contract, norm, partial density) plus the site updates the gate
+  classes perform on it (``cv_simulator/gates.py``: single-site operators :205-246, CZ :151-163, the bilinear plane
+  resampling of BS / CX :58-84,166-192, SWAP :48-55, Insert :24-45, homodyne read-out :87-117).
+
+Pinned by ``tests/golden/cv_mps.npz`` (site shapes, norms, contracted checkpoints, measurement records and reduced
+densities the reference produced with truncation on, including its randomized branch) in ``tests/test_mps_oracle.py``.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.interpolate import RegularGridInterpolator
+
+
+def range_finder(a: np.ndarray, probes: int, power_iterations: int, rng) -> np.ndarray:
+    """Orthonormal ``Q`` with ``Q Q^H a ~ a`` (mps.py:5-22); ``rng`` is a seed or a Generator, as upstream."""
+    gen = np.random.default_rng(rng)
+    q, _ = np.linalg.qr(a @ gen.normal(0, 1, size=(a.shape[1], probes)), "reduced")
+    for _ in range(power_iterations):
+        q, _ = np.linalg.qr(a.T.conj() @ q, "reduced")
+        q, _ = np.linalg.qr(a @ q, "reduced")
+    return q
+
+
+def randomized_svd(a: np.ndarray, k: int, rng=None):
+    """First ``k`` singular triplets through the range finder (mps.py:24-50): the wide case works on the transpose."""
+    power_iterations = 7 if k < 0.1 * min(a.shape) else 4
+    wide = a.shape[0] < a.shape[1]
+    tall = a.T if wide else a
+    q = range_finder(tall, k + 10, power_iterations, rng)
+    u, s, vh = np.linalg.svd(q.T.conj() @ tall)
+    u, s, vh = q @ u[:, :k], s[:k], vh[:k, :]
+    return (vh.T, s, u.T) if wide else (u, s, vh)
+
+
+def kept_rank(s: np.ndarray, max_bond_dim=np.inf, abs_err: float = 0, rel_err: float = 1e-12) -> int:
+    """mps.py:83-86: drop the longest tail whose sum stays within max(abs_err, rel_err * sum), then apply the cap."""
+    allowed = max(0, abs_err, sum(s) * rel_err)
+    r = int(np.sum(np.flip(s).cumsum() > allowed))
+    return int(min(r, len(s), max(0, max_bond_dim)))
+
+
+def split(matrix: np.ndarray, *, max_bond_dim=np.inf, abs_err: float = 0, rel_err: float = 1e-12, rng_seed=None):
+    """``tensor_svd`` on an already flattened matrix: ``(m1, m2)`` with ``m1 @ m2 ~ matrix``."""
+    if max_bond_dim * 10 < min(matrix.shape):
+        u, s, vh = randomized_svd(matrix, int(max_bond_dim), rng_seed)
+    else:
+        u, s, vh = np.linalg.svd(matrix, full_matrices=False)
+    r = kept_rank(s, max_bond_dim, abs_err, rel_err)
+    root = np.sqrt(s[:r])
+    return u[:, :r] * root, root[:, None] * vh[:r, :]
+
+
+class Chain:
+    """A list of ``(chi_l, d, chi_r)`` NumPy sites on the grid ``domain`` with the reference's update rules."""
+
+    def __init__(self, domain: np.ndarray, sites=()):
+        self.domain = np.asarray(domain)
+        self.diff = abs(domain[-1] - domain[0]) / (len(domain) - 1)
+        self.sites = [np.asarray(s).reshape(1, -1, 1) if np.ndim(s) == 1 else np.asarray(s) for s in sites]
+
+    def __len__(self):
+        return len(self.sites)
+
+    def shapes(self):
+        return [list(s.shape) for s in self.sites]
+
+    # ---- read-out (mps.py:163-190) -----------------------------------------------------------------------------
+    def contract(self) -> np.ndarray:
+        acc = self.sites[0]
+        for s in self.sites[1:]:
+            acc = np.tensordot(acc, s, axes=1)
+        return np.squeeze(acc)
+
+    def norm(self) -> float:
+        env = np.ones((1, 1))
+        for t in self.sites:
+            env = np.einsum("ab,aci,bcj -> ij", env, t, np.conj(t), optimize=True)
+        return float(np.sqrt(np.real(env[0, 0]) * self.diff ** len(self.sites)))
+
+    def partial_density(self, axis: int) -> np.ndarray:
+        left = np.ones((1, 1))
+        for t in self.sites[:axis]:
+            left = np.einsum("ab,aci,bcj -> ij", left, t, np.conj(t), optimize=True)
+        right = np.ones((1, 1))
+        for t in reversed(self.sites[axis + 1:]):
+            right = np.einsum("ica,jcb,ab -> ij", t, np.conj(t), right, optimize=True)
+        t = self.sites[axis]
+        rho = np.einsum("ab,aic,bjd,cd -> ij", left, t, np.conj(t), right, optimize=True)
+        return rho * self.diff ** (len(self.sites) - 1)
+
+    # ---- single-site updates (gates.py:205-246) ----------------------------------------------------------------
+    def apply_axis(self, index: int, matrix: np.ndarray) -> None:
+        self.sites[index] = np.moveaxis(np.tensordot(matrix, self.sites[index], [1, 1]), 0, 1)
+
+    def scale_axis(self, index: int, diag: np.ndarray) -> None:
+        self.sites[index] = self.sites[index] * np.asarray(diag)[None, :, None]
+
+    # ---- two-site updates --------------------------------------------------------------------------------------
+    def _pair(self, left: int) -> np.ndarray:
+        return np.tensordot(self.sites[left], self.sites[left + 1], axes=(2, 0))
+
+    def _store(self, left: int, theta: np.ndarray, **options) -> None:
+        cl, d, _, cr = theta.shape
+        m1, m2 = split(theta.reshape(cl * d, d * cr), **options)
+        self.sites[left], self.sites[left + 1] = m1.reshape(cl, d, -1), m2.reshape(-1, d, cr)
+
+    def plane_phase(self, left: int, plane: np.ndarray, **options) -> None:
+        """CZ: ``theta[a, j, l, b] *= plane[j, l]`` (gates.py:159-160)."""
+        self._store(left, self._pair(left) * plane[None, :, :, None], **options)
+
+    def plane_resample(self, left: int, x_src: np.ndarray, y_src: np.ndarray, **options) -> None:
+        """BS / CX: every (q_left, q_right) plane re-sampled at ``(x_src, y_src)``, bilinear, zero outside the grid
+        (gates.py:74-80,187-189)."""
+        theta, qs = self._pair(left), self.domain
+        for a in range(theta.shape[0]):
+            for b in range(theta.shape[3]):
+                interp = RegularGridInterpolator((qs, qs), theta[a, :, :, b], method="linear", bounds_error=False,
+                                                 fill_value=0)
+                theta[a, :, :, b] = interp((x_src, y_src))
+        self._store(left, theta, **options)
+
+    def swap(self, left: int, **options) -> None:
+        """SWAP: split the pair with the physical legs exchanged (gates.py:51-55)."""
+        self._store(left, np.swapaxes(self._pair(left), 1, 2), **options)
+
+    def insert(self, index: int, vec: np.ndarray, **options) -> None:
+        """Insert (gates.py:24-45): free-standing at the ends, otherwise attached to the site at ``index`` and split."""
+        if index in (0, len(self.sites)):
+            self.sites.insert(index, np.reshape(vec, (1, -1, 1)))
+            return
+        joined = np.einsum("i,ajb -> aijb", vec, self.sites[index])
+        cl, d, _, cr = joined.shape
+        m1, m2 = split(joined.reshape(cl * d, d * cr), **options)
+        self.sites[index] = m2.reshape(-1, d, cr)
+        self.sites.insert(index, m1.reshape(cl, d, -1))
+
+    def measure_q(self, index: int, forced: float):
+        """Homodyne read-out with a forced outcome (gates.py:90-117): returns ``(value, probability density)``."""
+        qs, dq = self.domain, self.diff
+        weights = np.real(np.diag(self.partial_density(index))) * dq
+        pick = int(np.argmin(np.abs(qs - forced)))
+        density = weights[pick] / dq
+        if len(self.sites) == 1:
+            return qs[pick], None
+        bond = self.sites[index][:, pick, :] / np.sqrt(density)
+        if np.argmax(bond.shape) == 0 and index != 0:
+            self.sites[index - 1] = np.tensordot(self.sites[index - 1], bond, axes=(2, 0))
+        else:
+            self.sites[index + 1] = np.tensordot(bond, self.sites[index + 1], axes=(1, 0))
+        self.sites.pop(index)
+        return qs[pick], density

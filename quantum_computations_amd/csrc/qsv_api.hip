@@ -815,6 +815,23 @@ int qsv_tensor_plane_gather(int device, void *hip_stream, const void *dev_in, vo
                                     dev_cols, static_cast<const double *>(dev_vals));
 }
 
+int qsv_tensor_plane_phase(int device, void *hip_stream, void *dev_theta, uint64_t L, uint64_t d, uint64_t R,
+                           const void *dev_grid, double strength) {
+    if (!dev_theta || !dev_grid) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (empty_site(L, d, R)) return qsv_fail(QSV_EINVAL, "empty tensor");
+    return qsvq_tensor_plane_phase(device, as_stream(hip_stream), amp(dev_theta), L, d, R,
+                                   static_cast<const double *>(dev_grid), strength);
+}
+
+int qsv_tensor_plane_affine(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d,
+                            uint64_t R, const void *dev_grid, const double *a) {
+    if (!dev_in || !dev_out || !dev_grid || !a) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (dev_in == dev_out) return qsv_fail(QSV_EINVAL, "in-place resampling is not supported: pass distinct buffers");
+    if (empty_site(L, d, R) || d < 2) return qsv_fail(QSV_EINVAL, "need a grid of at least two points");
+    return qsvq_tensor_plane_affine(device, as_stream(hip_stream), camp(dev_in), amp(dev_out), L, d, R,
+                                    static_cast<const double *>(dev_grid), a);
+}
+
 int qsv_tensor_take_level(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d,
                           uint64_t R, uint64_t level, double scale) {
     if (!dev_in || !dev_out) return qsv_fail(QSV_EINVAL, "null pointer");

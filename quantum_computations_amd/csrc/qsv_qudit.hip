@@ -590,6 +590,58 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_axis_overlap(const amp_t *__restr
     }
 }
 
+// theta[a, j, l, b] *= exp(i s q_j q_l): the CZ phases (gates.py:159) evaluated in the kernel -- no (d, d) table.
+__global__ __launch_bounds__(QSV_BLOCK) void k_plane_phase(amp_t *__restrict__ t, uint64_t total, int d, uint64_t R,
+                                                          const double *__restrict__ qs, double strength) {
+    for (uint64_t o = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t i1 = (o / R) % d, i0 = (o / (R * d)) % d;
+        double sn, cs;
+        sincos(strength * (qs[i0] * qs[i1]), &sn, &cs);
+        t[o] = cmul(cplx{cs, sn}, t[o]);
+    }
+}
+
+// Lower cell of x on the sorted grid qs the way RegularGridInterpolator finds it (searchsorted(grid, x) - 1, clipped
+// to [0, d - 2]) and the normalised distance into that cell.
+__device__ __forceinline__ int grid_cell(const double *__restrict__ qs, int d, double inv_dq, double x, double *frac) {
+    int i = static_cast<int>(floor((x - qs[0]) * inv_dq));
+    i = i < 0 ? 0 : (i > d - 2 ? d - 2 : i);
+    while (i > 0 && !(qs[i] < x)) --i;                 // largest i with qs[i] < x ...
+    while (i < d - 2 && qs[i + 1] < x) ++i;            // ... within the clip range
+    *frac = (x - qs[i]) / (qs[i + 1] - qs[i]);
+    return i;
+}
+
+// out[a, i0, i1, b] = bilinear interpolation of the plane in[a, :, :, b] at the affine image of (q_i0, q_i1),
+// zero outside the grid: the RegularGridInterpolator loop of BS / CX (gates.py:74-80,187-189) for every bond pair at
+// once, with the four source points and weights computed in the kernel instead of read from a 48-byte-per-point table.
+__global__ __launch_bounds__(QSV_BLOCK) void k_plane_affine(const amp_t *__restrict__ in, amp_t *__restrict__ out,
+                                                           uint64_t L, int d, uint64_t R,
+                                                           const double *__restrict__ qs, double a00, double a01,
+                                                           double a10, double a11) {
+    const uint64_t total = L * d * d * R;
+    const uint64_t s1 = R, s0 = R * d, sl = R * d * d;
+    const double lo = qs[0], hi = qs[d - 1], inv_dq = (d - 1) / (hi - lo);
+    for (uint64_t o = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t r = o % R, i1 = (o / s1) % d, i0 = (o / s0) % d, l = o / sl;
+        const double x = qs[i0], y = qs[i1];
+        const double xs = a00 * x + a01 * y, ys = a10 * x + a11 * y;
+        amp_t acc = {0.0, 0.0};
+        if (xs >= lo && xs <= hi && ys >= lo && ys <= hi) {
+            double f0, f1;
+            const int j0 = grid_cell(qs, d, inv_dq, xs, &f0), j1 = grid_cell(qs, d, inv_dq, ys, &f1);
+            const amp_t *p = in + l * sl + r + j0 * s0 + j1 * s1;
+            const amp_t v00 = p[0], v01 = p[s1], v10 = p[s0], v11 = p[s0 + s1];
+            const double w00 = (1 - f0) * (1 - f1), w01 = (1 - f0) * f1, w10 = f0 * (1 - f1), w11 = f0 * f1;
+            acc.x = w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x;
+            acc.y = w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
+        }
+        out[o] = acc;
+    }
+}
+
 }  // namespace
 
 int qsvq_tensor_scale_axis(int device, hipStream_t stream, amp_t *t, uint64_t L, uint64_t d, uint64_t R,
@@ -643,5 +695,24 @@ int qsvq_tensor_axis_overlap(int device, hipStream_t stream, const amp_t *z, con
     QSV_HIP(hipSetDevice(device));
     hipLaunchKernelGGL(k_axis_overlap, dim3(static_cast<unsigned>(d)), dim3(QSV_BLOCK), 0, stream, z, t, L,
                        static_cast<int>(d), R, dev_out);
+    return check_launch();
+}
+
+int qsvq_tensor_plane_phase(int device, hipStream_t stream, amp_t *t, uint64_t L, uint64_t d, uint64_t R,
+                            const double *dev_qs, double strength) {
+    QSV_HIP(hipSetDevice(device));
+    const uint64_t total = L * d * d * R;
+    const int grid = grid_of(total, QSV_BLOCK * 4, 1 << 16);
+    hipLaunchKernelGGL(k_plane_phase, dim3(grid), dim3(QSV_BLOCK), 0, stream, t, total, static_cast<int>(d), R, dev_qs,
+                       strength);
+    return check_launch();
+}
+
+int qsvq_tensor_plane_affine(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d,
+                             uint64_t R, const double *dev_qs, const double *a) {
+    QSV_HIP(hipSetDevice(device));
+    const int grid = grid_of(L * d * d * R, QSV_BLOCK, 1 << 18);
+    hipLaunchKernelGGL(k_plane_affine, dim3(grid), dim3(QSV_BLOCK), 0, stream, in, out, L, static_cast<int>(d), R,
+                       dev_qs, a[0], a[1], a[2], a[3]);
     return check_launch();
 }

@@ -20,6 +20,7 @@ Constructor signatures, ``repr`` strings, sign conventions (index order, ``dagge
 from __future__ import annotations
 
 import logging
+from collections import OrderedDict
 
 import numpy as np
 
@@ -38,15 +39,23 @@ def _truncation(gate, mps, rng=None) -> dict:
     return dict(gate.svd_options, rng_seed=rng) if mps.layout == "sites" else {}
 
 
+_OPERATORS: "OrderedDict[tuple, object]" = OrderedDict()      # host operators shared by equal gates (LRU)
+_OPERATORS_KEPT = 16
+
+
 def _cached(gate, name: str, domain: np.ndarray, build):
-    """Host operators depend only on the gate's parameters and the grid: build once per (gate, grid) so that repeated
-    ``apply`` calls hand the register the same array object (which it keeps resident on the device)."""
-    key = (name, domain[0], domain[-1], len(domain))
-    store = gate.__dict__.setdefault("_operator_cache", {})
-    if key not in store:
-        store.clear()
-        store[key] = build()
-    return store[key]
+    """Host operators depend only on the gate's class, parameters and the grid: build once and hand every equal gate
+    the same array object (which the registers keep resident on the device), so that a circuit of many ``F`` /
+    ``X(sqrt(pi))`` gates pays for the ``d x d`` matrix once."""
+    key = (type(gate).__name__, name, repr(gate.arg), bool(gate.dagger), getattr(gate, "angle", None),
+           getattr(gate, "index1", 0) < getattr(gate, "index2", 1), float(domain[0]), float(domain[-1]), len(domain))
+    if key in _OPERATORS:
+        _OPERATORS.move_to_end(key)
+    else:
+        _OPERATORS[key] = build()
+        while len(_OPERATORS) > _OPERATORS_KEPT:
+            _OPERATORS.popitem(last=False)
+    return _OPERATORS[key]
 
 
 def _pi_fraction(angle: float) -> str:
@@ -150,11 +159,19 @@ class _PlaneResampling(TwoModeGate):
     """Two-mode gate that re-samples the (q_left, q_right) plane at ``source_points(x, y)`` with bilinear weights --
     the per-bond-pair ``RegularGridInterpolator`` loop of the reference (``gates.py:74-80,187-189``) as one table."""
 
-    def source_points(self, x: np.ndarray, y: np.ndarray):
+    def affine_map(self) -> tuple[float, float, float, float]:
+        """``(a00, a01, a10, a11)``: output point ``(x, y)`` reads the input plane at ``(a00 x + a01 y, a10 x + a11 y)``."""
         raise NotImplementedError
+
+    def source_points(self, x: np.ndarray, y: np.ndarray):
+        a00, a01, a10, a11 = self.affine_map()
+        return a00 * x + a01 * y, a10 * x + a11 * y
 
     def apply(self, mps: MPS, rng=None, **_):
         grid = mps.domain
+        if mps.layout == "sites":          # the site register evaluates the map in the kernel: no table
+            mps.reg.apply_plane_affine(grid, self.affine_map(), self.left_index, **_truncation(self, mps, rng))
+            return
 
         def table():
             x, y = np.meshgrid(grid, grid, indexing="ij")
@@ -173,9 +190,9 @@ class BS(_PlaneResampling):
     def __repr__(self):
         return f"{type(self).__name__}{_pi_fraction(self.arg)}_{self.index1},{self.index2}"
 
-    def source_points(self, x, y):
+    def affine_map(self):
         theta = self.arg * (1 if self.index1 < self.index2 else -1) * (-1 if self.dagger else 1)
-        return np.cos(theta) * x + np.sin(theta) * y, np.cos(theta) * y - np.sin(theta) * x
+        return np.cos(theta), np.sin(theta), -np.sin(theta), np.cos(theta)
 
 
 class CX(_PlaneResampling):
@@ -187,11 +204,11 @@ class CX(_PlaneResampling):
     def __repr__(self):
         return Gate.__repr__(self) + f"_{self.index1},{self.index2}"
 
-    def source_points(self, x, y):
-        sign = -1 if self.dagger else 1
-        if self.index1 < self.index2:        # the left mode controls
-            return x, y - sign * x
-        return x - sign * y, y
+    def affine_map(self):
+        sign = -1.0 if self.dagger else 1.0
+        if self.index1 < self.index2:        # the left mode controls: (x, y - sign x)
+            return 1.0, 0.0, -sign, 1.0
+        return 1.0, -sign, 0.0, 1.0          # (x - sign y, y)
 
 
 class SWAP(TwoModeGate):
@@ -212,6 +229,9 @@ class CZ(TwoModeGate):
 
     def apply(self, mps: MPS, rng=None, **_):
         strength = -self.arg if self.dagger else self.arg
+        if mps.layout == "sites":          # phases evaluated in the kernel
+            mps.reg.apply_plane_phase(mps.domain, strength, self.left_index, **_truncation(self, mps, rng))
+            return
         plane = _cached(self, "plane", mps.domain, lambda: np.exp(1j * strength * np.outer(mps.domain, mps.domain)))
         mps.reg.apply_two_mode(plane, self.left_index, self.right_index, **_truncation(self, mps, rng))
 

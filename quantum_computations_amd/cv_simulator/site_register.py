@@ -11,7 +11,7 @@ step                                  entry point
 single-mode operator on a site        ``qsv_tensor_apply_axis_dev`` (rocBLAS zgemm for grids >= 64 points)
 single-mode phases (Z, P)             ``qsv_tensor_scale_axis``
 theta = site_l . site_r               ``qsv_tensor_gemm``
-CZ phases / BS, CX, SWAP resampling   ``qsv_tensor_plane_diag`` / ``qsv_tensor_plane_gather``
+CZ phases / BS, CX resampling / SWAP   ``qsv_tensor_plane_phase`` / ``qsv_tensor_plane_affine`` / ``qsv_tensor_plane_gather``
 split + truncate                      ``qsv_tensor_svd_split`` / ``qsv_tensor_rsvd_split`` (rocSOLVER + the reference's rule)
 homodyne read-out                     ``qsv_tensor_gemm`` environments + ``qsv_tensor_axis_overlap``; ``qsv_tensor_take_level``
 Insert in the middle of the chain     ``qsv_tensor_insert_axis`` + ``qsv_tensor_svd_split``
@@ -260,6 +260,24 @@ class SiteRegister:
         mapped = self._empty(cl * d, d * cr)
         _lib.call("qsv_tensor_plane_gather", self.device, self._stream(), self._p(theta), self._p(mapped), cl, d, cr,
                   per_point, self._p(dev_cols), self._p(dev_vals))
+        m1, m2, r = self._split(mapped, cl * d, d * cr, **truncation)
+        self._store_pair(left, m1, m2, cl, cr, r)
+
+    def apply_plane_phase(self, grid: np.ndarray, strength: float, left: int, **truncation) -> None:
+        """CZ with the phases ``exp(i strength q_j q_l)`` evaluated in the kernel (no ``(d, d)`` table)."""
+        theta, cl, d, cr = self._two_site(left)
+        _lib.call("qsv_tensor_plane_phase", self.device, self._stream(), self._p(theta), cl, d, cr,
+                  self._p(self._keep(grid, np.float64)), float(strength))
+        m1, m2, r = self._split(theta, cl * d, d * cr, **truncation)
+        self._store_pair(left, m1, m2, cl, cr, r)
+
+    def apply_plane_affine(self, grid: np.ndarray, coefficients, left: int, **truncation) -> None:
+        """BS / CX: resample every plane at ``(a00 x + a01 y, a10 x + a11 y)``, bilinear, computed in the kernel."""
+        theta, cl, d, cr = self._two_site(left)
+        mapped = self._empty(cl * d, d * cr)
+        a = (C.c_double * 4)(*[float(v) for v in coefficients])
+        _lib.call("qsv_tensor_plane_affine", self.device, self._stream(), self._p(theta), self._p(mapped), cl, d, cr,
+                  self._p(self._keep(grid, np.float64)), a)
         m1, m2, r = self._split(mapped, cl * d, d * cr, **truncation)
         self._store_pair(left, m1, m2, cl, cr, r)
 
