@@ -229,6 +229,11 @@ int qsv_tensor_take_level(int device, void *hip_stream, const void *dev_in, void
 /* out[l, j, r] = vec[j] * in[l, r]: np.einsum("i,ajb -> aijb") of Insert.apply (gates.py:39). */
 int qsv_tensor_insert_axis(int device, void *hip_stream, const void *dev_in, void *dev_out, uint64_t L, uint64_t d,
                            uint64_t R, const void *dev_vec /* d */);
+/* out[x, y, z, w] = p[x, z] * q[y, w] (out[x, y, w, z] when swap_last != 0), p is (X x Z), q is (Y x W): the outer
+ * products that attach the two halves of a GKP Bell pair to their neighbouring sites with the bond legs adjacent
+ * (InsertBell.apply, gkp_simulator/insert_bell.py:80-90), ready for qsv_tensor_svd_split. */
+int qsv_tensor_outer(int device, void *hip_stream, const void *dev_p, const void *dev_q, void *dev_out, uint64_t X,
+                     uint64_t Y, uint64_t Z, uint64_t W, int swap_last);
 /* out[j] = Re sum_{l, r} z[l, j, r] conj(t[l, j, r]) (d doubles in device memory): the diagonal of the reduced
  * density matrix once both environments are contracted into z (mps.py:188-189). */
 int qsv_tensor_axis_overlap(int device, void *hip_stream, const void *dev_z, const void *dev_t, uint64_t L, uint64_t d,

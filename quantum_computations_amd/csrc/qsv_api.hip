@@ -847,6 +847,14 @@ int qsv_tensor_insert_axis(int device, void *hip_stream, const void *dev_in, voi
                                    static_cast<const double *>(dev_vec));
 }
 
+int qsv_tensor_outer(int device, void *hip_stream, const void *dev_p, const void *dev_q, void *dev_out, uint64_t X,
+                     uint64_t Y, uint64_t Z, uint64_t W, int swap_last) {
+    if (!dev_p || !dev_q || !dev_out) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (X == 0 || Y == 0 || Z == 0 || W == 0) return qsv_fail(QSV_EINVAL, "empty tensor");
+    return qsvq_tensor_outer(device, as_stream(hip_stream), camp(dev_p), camp(dev_q), amp(dev_out), X, Y, Z, W,
+                             swap_last);
+}
+
 int qsv_tensor_axis_overlap(int device, void *hip_stream, const void *dev_z, const void *dev_t, uint64_t L, uint64_t d,
                             uint64_t R, void *dev_out) {
     if (!dev_z || !dev_t || !dev_out) return qsv_fail(QSV_EINVAL, "null pointer");

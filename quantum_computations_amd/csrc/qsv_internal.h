@@ -139,6 +139,8 @@ int qsvq_tensor_plane_phase(int device, hipStream_t stream, amp_t *t, uint64_t L
                             const double *dev_qs, double strength);
 int qsvq_tensor_plane_affine(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d,
                              uint64_t R, const double *dev_qs, const double *a);
+int qsvq_tensor_outer(int device, hipStream_t stream, const amp_t *p, const amp_t *q, amp_t *out, uint64_t X, uint64_t Y,
+                      uint64_t Z, uint64_t W, int swap_last);
 int qsvq_tensor_take_level(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d,
                            uint64_t R, uint64_t level, double scale);
 int qsvq_tensor_insert_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d,

@@ -642,6 +642,22 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_plane_affine(const amp_t *__restr
     }
 }
 
+// out[x, y, z, w] = p[x, z] * q[y, w]  (or out[x, y, w, z] with swap_last): the two outer products of InsertBell.apply
+// (gkp_simulator/insert_bell.py:80,87 -- "aib,kd -> aikbd" and "dl,bjc -> bdljc") with the bond legs kept adjacent.
+__global__ __launch_bounds__(QSV_BLOCK) void k_outer(const amp_t *__restrict__ p, const amp_t *__restrict__ q,
+                                                    amp_t *__restrict__ out, uint64_t X, uint64_t Y, uint64_t Z,
+                                                    uint64_t W, int swap_last) {
+    const uint64_t total = X * Y * Z * W;
+    for (uint64_t o = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t last = swap_last ? Z : W, mid = swap_last ? W : Z;
+        const uint64_t i3 = o % last, i2 = (o / last) % mid, y = (o / (last * mid)) % Y, x = o / (last * mid * Y);
+        const uint64_t z = swap_last ? i3 : i2, w = swap_last ? i2 : i3;
+        const amp_t a = p[x * Z + z], b = q[y * W + w];
+        out[o] = cmul(cplx{a.x, a.y}, b);
+    }
+}
+
 }  // namespace
 
 int qsvq_tensor_scale_axis(int device, hipStream_t stream, amp_t *t, uint64_t L, uint64_t d, uint64_t R,
@@ -714,5 +730,13 @@ int qsvq_tensor_plane_affine(int device, hipStream_t stream, const amp_t *in, am
     const int grid = grid_of(L * d * d * R, QSV_BLOCK, 1 << 18);
     hipLaunchKernelGGL(k_plane_affine, dim3(grid), dim3(QSV_BLOCK), 0, stream, in, out, L, static_cast<int>(d), R,
                        dev_qs, a[0], a[1], a[2], a[3]);
+    return check_launch();
+}
+
+int qsvq_tensor_outer(int device, hipStream_t stream, const amp_t *p, const amp_t *q, amp_t *out, uint64_t X, uint64_t Y,
+                      uint64_t Z, uint64_t W, int swap_last) {
+    QSV_HIP(hipSetDevice(device));
+    const int grid = grid_of(X * Y * Z * W, QSV_BLOCK, 1 << 16);
+    hipLaunchKernelGGL(k_outer, dim3(grid), dim3(QSV_BLOCK), 0, stream, p, q, out, X, Y, Z, W, swap_last);
     return check_launch();
 }

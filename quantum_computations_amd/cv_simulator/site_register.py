@@ -316,3 +316,62 @@ class SiteRegister:
         m1, m2, r = self._split(joined, cl * d, d * cr, **truncation)
         self.sites[mode] = m2.reshape(r, d, cr)
         self.sites.insert(mode, m1.reshape(cl, d, r))
+
+    # ---- GKP layer (gkp_simulator) ----------------------------------------------------------------------------
+    def _outer(self, p, q, x: int, y: int, z: int, w: int, swap_last: bool):
+        out = self._empty(x * y, z * w)
+        _lib.call("qsv_tensor_outer", self.device, self._stream(), self._p(p), self._p(q), self._p(out), x, y, z, w,
+                  int(swap_last))
+        return out
+
+    def insert_bond_pair(self, mode: int, first: np.ndarray, second: np.ndarray, **truncation) -> None:
+        """Insert two new modes at ``mode`` that share a bond: ``first`` is ``(d, chi)``, ``second`` ``(chi, d)`` (a GKP
+        Bell pair has chi = 2).  At the ends of the chain they are simply attached; inside, each half is multiplied into
+        its neighbour and split off again (``InsertBell.apply``, gkp_simulator/insert_bell.py:60-96)."""
+        d, chi = first.shape
+        if mode == 0 or mode == len(self.sites):
+            pair = [self._upload(first.reshape(1, d, chi)), self._upload(second.reshape(chi, d, 1))]
+            self.sites[mode:mode] = pair
+            return
+        t1, t2 = self.sites[mode - 1], self.sites[mode]
+        a, _, b = (int(v) for v in t1.shape)
+        c = int(t2.shape[2])
+        # [(a, i), k, b, dd] = t1[(a, i), b] * first[k, dd]  ->  rows (a, i), columns (k, b, dd)
+        joined = self._outer(t1, self._upload(first), a * d, d, b, chi, swap_last=False)
+        m1, m2, r1 = self._split(joined, a * d, d * b * chi, **truncation)
+        new_t1, new_first = m1.reshape(a, d, r1), m2.reshape(r1, d, b * chi)
+        # [b, dd, l, (j, c)] = second[dd, l] * t2[b, (j, c)]  ->  rows (b, dd, l), columns (j, c)
+        joined = self._outer(t2, self._upload(second), b, chi, d * c, d, swap_last=True)
+        m1, m2, r2 = self._split(joined, b * chi * d, d * c, **truncation)
+        new_second, new_t2 = m1.reshape(b * chi, d, r2), m2.reshape(r2, d, c)
+        self.sites[mode - 1:mode + 1] = [new_t1, new_first, new_second, new_t2]
+
+    def operator_string_coefficients(self, operators: list[np.ndarray]) -> np.ndarray:
+        """``C[i_0, ..., i_{m-1}] = <psi| O_{i_0} (x) ... (x) O_{i_{m-1}} |psi>`` (no grid-measure factors) for every
+        string over the given single-mode operators: the contraction loop of ``full_logical_density_mps``
+        (gkp_simulator/utils.py:82-90) as a depth-first walk that shares the environments of common prefixes."""
+        n, k = len(self.sites), len(operators)
+        dressed = []
+        for t in self.sites:
+            cl, d, cr = (int(v) for v in t.shape)
+            row = []
+            for op in operators:
+                out = self._empty(cl, d, cr)
+                _lib.call("qsv_tensor_apply_axis_dev", self.device, self._stream(), self._p(t), self._p(out), cl, d, d, cr,
+                          self._p(self._keep(op)))
+                row.append(out)
+            dressed.append(row)
+        result = np.zeros((k,) * n, dtype=np.complex128)
+
+        def walk(level: int, g, prefix: tuple):
+            if level == n:
+                result[prefix] = np.conj(g.cpu().numpy()[0, 0])
+                return
+            bra = self.sites[level]
+            cl, d, cr = (int(v) for v in bra.shape)
+            for i in range(k):
+                x = self._gemm(g, OP_CONJ_TRANSPOSE, dressed[level][i], OP_NONE, cl, d * cr, cl)
+                walk(level + 1, self._gemm(x, OP_CONJ_TRANSPOSE, bra, OP_NONE, cr, cr, cl * d), prefix + (i,))
+
+        walk(0, self._upload(np.ones((1, 1))), ())
+        return result

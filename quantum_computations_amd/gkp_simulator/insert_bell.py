@@ -1,0 +1,73 @@
+"""GKP Bell pairs as two-site matrix-product states (``simulators/gkp_simulator/insert_bell.py:15-96``).
+
+The pair ``BS |ø>|ø>`` (two qunaught states through a balanced beam splitter) equals
+``2^{-1/2} (|0>|0> + c |1>|1>)`` in the GKP code words, i.e. a chain of two sites joined by a bond of dimension 2 -- no
+beam splitter has to be simulated to prepare it.  ``c = 1`` for the plain pair, ``e^{±i pi/8}`` for the pairs that
+teleport a T / T^dagger gate.
+"""
+from __future__ import annotations
+
+import logging
+from enum import Enum
+
+import numpy as np
+
+from ..cv_simulator.gates import Insert
+from ..cv_simulator.mps import MPS
+from ..cv_simulator.states import State
+
+logger = logging.getLogger(__name__)
+
+PI = np.pi
+SQPI = np.sqrt(np.pi)
+
+
+class GKPBellState(Enum):
+    PLUS = 1
+    T = 2
+    Tdg = 3
+
+    def __repr__(self):
+        return "GKP_BELL_" + self.name
+
+    __str__ = __repr__
+
+    @property
+    def _second_weight(self) -> complex:
+        return {"PLUS": 1.0, "T": np.exp(1j * PI / 8), "Tdg": np.exp(-1j * PI / 8)}[self.name]
+
+    def halves(self, qs: np.ndarray, gkp_epsilon: float = None) -> tuple[np.ndarray, np.ndarray]:
+        """``(first, second)``: the ``(d, 2)`` and ``(2, d)`` matrices whose product over the bond is the pair's
+        wavefunction ``psi[q_1, q_2]``."""
+        if not isinstance(qs, np.ndarray) or qs.ndim != 1:
+            raise TypeError("qs must be a 1D numpy array.")
+        if not np.allclose(np.diff(qs, 2), 0, atol=np.finfo(qs.dtype).eps ** 0.5):
+            raise ValueError("qs is not an arithmetic progression.")
+        if gkp_epsilon is not None and gkp_epsilon <= 0:
+            raise ValueError("epsilon must be a positive real number")
+        first = np.empty((len(qs), 2), dtype=complex)
+        first[:, 0] = 2 ** (-1 / 4) * State.GKP_ZERO.eval(qs, gkp_epsilon)
+        first[:, 1] = 2 ** (-1 / 4) * self._second_weight * State.GKP_ONE.eval(qs, gkp_epsilon)
+        return first, np.ascontiguousarray(first.T)
+
+    def eval(self, qs: np.ndarray, gkp_epsilon: float = None, *, device: int = 0) -> MPS:
+        """The pair as a two-mode register (sites ``(1, d, 2)`` and ``(2, d, 1)``)."""
+        first, second = self.halves(qs, gkp_epsilon)
+        return MPS(qs, [first[None, :, :], second[:, :, None]], device=device, layout="sites")
+
+
+class InsertBell(Insert):
+    """Insert a two-mode GKP Bell pair at ``index`` (the pair occupies ``index`` and ``index + 1`` afterwards)."""
+
+    def __init__(self, index, state: GKPBellState = GKPBellState.PLUS, *, gkp_epsilon: float = None, **kwargs):
+        if not isinstance(state, GKPBellState):
+            raise TypeError(f"Expected GKPBellState obj but found {type(state)}")
+        super().__init__(index, state, gkp_epsilon=gkp_epsilon, **kwargs)
+
+    def apply(self, mps: MPS, rng=None, **_):
+        if self.index < 0 or self.index > len(mps):
+            raise IndexError(f"Cannot insert mode at index {self.index} for MPS of length {len(mps)}")
+        if mps.layout != "sites":
+            raise NotImplementedError("InsertBell needs a matrix-product register: build the MPS with layout='sites'")
+        first, second = self.arg.halves(mps.domain, self.gkp_epsilon)
+        mps.reg.insert_bond_pair(self.index, first, second, **dict(self.svd_options, rng_seed=rng))

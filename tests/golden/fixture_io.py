@@ -59,3 +59,13 @@ def cv_mps_program(cv, State, options):
             cv.Insert(1, State.GKP_ONE, gkp_epsilon=0.3, **options), cv.CZ(2, 1, 0.4, dagger=True, **options),
             cv.BS(3, 2, 0.3, **options), cv.Z(0, 1.1), cv.Homodyne(2, 0.4, 0.8), cv.D(0, [0.3, -0.2]),
             cv.CX(1, 2, 0.7, **options), cv.F(1, dagger=True), cv.Mp(0, -0.5)]
+
+
+def gkp_programs(dv):
+    """Qubit circuits for the GKP fixtures, from a gate module (the reference's here, ours in the tests)."""
+    return {
+        "h_cz_p": [dv.H(0), dv.CZ(0, 1), dv.P(1), dv.X(0)],
+        "t_branch": [dv.H(0), dv.T(0), dv.H(0), dv.Z(1), dv.Tdg(1)],
+        "swap_mix": [dv.H(1), dv.SWAP(0, 1), dv.Pdg(0), dv.Y(1), dv.CZ(1, 0), dv.I(0)],
+        "three": [dv.H(0), dv.H(2), dv.CZ(1, 2), dv.T(1), dv.SWAP(0, 1), dv.X(2), dv.P(0)],
+    }

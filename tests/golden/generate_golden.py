@@ -24,7 +24,7 @@ sys.path.insert(0, str(REPO))
 sys.path.insert(0, str(HERE))
 sys.path.insert(0, str(REFERENCE))
 
-from fixture_io import cv_mps_program, pack_ops  # noqa: E402
+from fixture_io import cv_mps_program, gkp_programs, pack_ops  # noqa: E402
 from quantum_computations_amd import workloads as W  # noqa: E402
 
 # --- the reference (untrusted public code: imported to be RUN, nothing is copied) ---------------------------
@@ -444,6 +444,156 @@ def gen_cv_mps():
     save("cv_mps.npz", cases=json.dumps(cases), **arrays)
 
 
+def import_reference_gkp():
+    """``simulators.gkp_simulator`` needs Python >= 3.12 for two PEP 695 statements (``type Syndrome = ...``,
+    ``type GKPEC = MBI``, gates.py:12,211); this container runs 3.10.  The loader below feeds the interpreter the file
+    with those two statements spelled as plain assignments -- the same meaning -- in memory only."""
+    import importlib.abc
+    import importlib.machinery
+    import importlib.util
+    import re
+
+    class Loader(importlib.machinery.SourceFileLoader):
+        def get_data(self, path):
+            data = super().get_data(path)
+            if str(path).endswith(".py"):
+                data = re.sub(rb"(?m)^type (\w+) = ", rb"\1 = ", data)
+            return data
+
+    class Finder(importlib.abc.MetaPathFinder):
+        def find_spec(self, name, path, target=None):
+            if not name.startswith("simulators.gkp_simulator"):
+                return None
+            rel = Path(*name.split("."))
+            for candidate, is_pkg in ((REFERENCE / rel / "__init__.py", True), (REFERENCE / rel.with_suffix(".py"), False)):
+                if candidate.exists():
+                    return importlib.util.spec_from_file_location(
+                        name, candidate, loader=Loader(name, str(candidate)),
+                        submodule_search_locations=[str(candidate.parent)] if is_pkg else None)
+            return None
+
+    sys.dont_write_bytecode = True
+    sys.meta_path.insert(0, Finder())
+    from simulators.gkp_simulator import gates as g, insert_bell as b, simulator as s, transpiler as t, utils as u
+    return g, b, s, t, u
+
+
+def gen_gkp():
+    """Measurement-based GKP layer: utilities, layering, frame commutation, gadgets with forced
+    outcomes, whole seeded simulations and logical read-out, all from the reference run through the loader above."""
+    g, b, sim_mod, t, u = import_reference_gkp()
+    from simulators.cv_simulator.simulator import Simulator as RefCVSimulator
+
+    arrays, cases = {}, {}
+    cases["eps2db"] = [[e, float(u.eps2db(e))] for e in (0.05, 0.1, 0.3, 0.7)]
+    cases["db2eps"] = [[x, float(u.db2eps(x))] for x in (6.0, 10.0, 14.5)]
+    cases["format_result"] = [[v, u.format_result(v)] for v in (0.0, 1.3, -2.71, 4.0)]
+    cases["cv2dv"] = [[v, bool(u.cv2dv_information(v))] for v in (0.1, 1.7, -1.9, 3.6, 5.2)]
+    arrays["syndrome_matrix"] = np.asarray(u.syndrome_matrix([(1, 0), (0, 1), (1, 1)]), dtype=np.complex128)
+
+    programs = gkp_programs(ref_gates)
+    cases["layering"] = {}
+    for name, gates in programs.items():
+        circ = t.MBGKPCircuit.transpile(gates)
+        filled = t.MBGKPCircuit.transpile(gates)
+        filled.fill()
+        cases["layering"][name] = {"text": circ.to_string(), "depth": circ.depth(), "count": circ.count(),
+                                   "filled": filled.to_string(), "filled_count": filled.count()}
+
+    frames = [[(0, 0), (1, 0)], [(1, 1), (0, 1)], [(1, 0), (1, 1)]]
+    table = []
+    for label, make in [("I", lambda: ref_gates.I(0)), ("T", lambda: ref_gates.T(0)), ("Tdg", lambda: ref_gates.Tdg(1)),
+                        ("H", lambda: ref_gates.H(1)), ("P", lambda: ref_gates.P(0)), ("Pdg", lambda: ref_gates.Pdg(1)),
+                        ("CZ", lambda: ref_gates.CZ(0, 1)), ("SWAP", lambda: ref_gates.SWAP(1, 0))]:
+        for frame in frames:
+            out_frame, out_gate = sim_mod.commute(make(), frame)
+            table.append({"gate": label, "frame": frame, "out": [list(p) for p in out_frame], "applied": repr(out_gate)})
+    cases["commute"] = table
+
+    syn = []
+    rng = np.random.default_rng(31)
+    for label, make in [("MBI", lambda: g.MBI(0)), ("MBF", lambda: g.MBF(0)), ("MBFdg", lambda: g.MBF(0, dagger=True)),
+                        ("MBP", lambda: g.MBP(1)), ("MBPdg", lambda: g.MBP(1, dagger=True)), ("MBT", lambda: g.MBT(0)),
+                        ("MBTdg", lambda: g.MBT(0, dagger=True)), ("MBCZ", lambda: g.MBCZ(0, 1)),
+                        ("MBSWAP", lambda: g.MBSWAP(2, 1))]:
+        gadget = make()
+        for _ in range(4):
+            results = list(rng.normal(0, 2.5, size=2 * len(gadget.indices)))
+            out, idx = gadget.compute_syndrome(results)
+            syn.append({"gadget": label, "results": results, "syndromes": [list(x) for x in out], "indices": list(idx),
+                        "compiled": [repr(c) for c in gadget.compile()], "angles": [float(a) for a in gadget.angles()]})
+    cases["syndromes"] = syn
+
+    # --- numerics on a small grid ---------------------------------------------------------------------------
+    d, eps = 60, 0.4
+    qs = np.linspace(-8.5, 8.5, d)
+    arrays["qs"] = qs
+    options = {"rel_err": 1e-9}
+    for name in ("PLUS", "T", "Tdg"):
+        arrays[f"bell_{name}"] = np.asarray(b.GKPBellState[name].eval(qs, eps).contract(), dtype=np.complex128)
+
+    # InsertBell in the middle / at the ends of a chain
+    from simulators.cv_simulator.states import State as RefCVState
+    qs_small = np.linspace(-6.0, 6.0, 14)          # four modes are contracted below: keep the fixture small
+    arrays["qs_small"] = qs_small
+    chain = RefMPS(qs_small, [RefCVState.GKP_PLUS.eval(qs_small, eps), RefCVState.GKP_ZERO.eval(qs_small, eps)])
+    ref_cv.CZ(0, 1, 1.0, **options).apply(chain)
+    b.InsertBell(1, b.GKPBellState.T, gkp_epsilon=eps, **options).apply(chain, rng=None)
+    arrays["insert_bell_mid"] = np.asarray(chain.contract(), dtype=np.complex128)
+    cases["insert_bell_mid_shapes"] = [list(x.shape) for x in chain.tensors]
+
+    # gadgets with forced outcomes on code-word inputs
+    forced = []
+    for label, make, inputs in [
+            ("MBF", lambda r: g.MBF(0, eps, results=r, **options), ["GKP_ZERO"]),
+            ("MBP", lambda r: g.MBP(1, eps, results=r, **options), ["GKP_PLUS", "GKP_PLUS"]),
+            ("MBT", lambda r: g.MBT(0, eps, results=r, **options), ["GKP_PLUS", "GKP_ZERO"]),
+            ("MBTdg", lambda r: g.MBT(0, eps, results=r, dagger=True, **options), ["GKP_PLUS"]),
+            ("MBCZ", lambda r: g.MBCZ(0, 1, eps, results=r, **options), ["GKP_PLUS", "GKP_PLUS"]),
+            ("MBSWAP", lambda r: g.MBSWAP(1, 0, eps, results=r, **options), ["GKP_ZERO", "GKP_PLUS"])]:
+        n_meas = 2 if label in ("MBF", "MBP", "MBT", "MBTdg") else 4
+        results = tuple(float(x) for x in rng.normal(0, 0.6, size=n_meas))
+        gadget = make(results)
+        mps = RefMPS(qs, [RefCVState[s].eval(qs, eps) for s in inputs])
+        runner = RefCVSimulator(gadget.compile(), rng_seed=1)
+        out = runner.run(mps)
+        key = f"gadget_{label}"
+        arrays[key] = np.asarray(out.contract(), dtype=np.complex128)
+        forced.append({"gadget": label, "inputs": inputs, "results": list(results), "key": key,
+                       "measured": [[r.result, r.probability] for r in runner.results],
+                       "shapes": [list(x.shape) for x in out.tensors]})
+    cases["forced_gadgets"] = forced
+
+    # whole seeded simulations: register, frame, logical density matrix
+    runs = []
+    for name, inputs, seed in [("h_cz_p", ["ZERO", "PLUS"], 3), ("t_branch", ["PLUS", "ZERO"], 8),
+                               ("swap_mix", ["ONE", "PLUS"], 5)]:
+        circ = t.MBGKPCircuit.transpile(gkp_programs(ref_gates)[name])
+        simulator = sim_mod.Simulator(circ, eps, rng_seed=seed, svd_options=options)
+        init = t.parse_to_mps([RefState[s] for s in inputs], eps, qs)
+        out, frame = simulator.run(init)
+        arrays[f"run_{name}_state"] = np.asarray(out.contract(), dtype=np.complex128)
+        arrays[f"run_{name}_rho"] = np.asarray(u.full_logical_density_mps(out), dtype=np.complex128)
+        arrays[f"run_{name}_rho_normalised"] = np.asarray(u.full_logical_density_mps(out, normalised=True),
+                                                          dtype=np.complex128)
+        runs.append({"name": name, "inputs": inputs, "seed": seed, "frame": [list(p) for p in frame],
+                     "shapes": [list(x.shape) for x in out.tensors]})
+    alt = sim_mod.SimulatorAlt(t.MBGKPCircuit.transpile(gkp_programs(ref_gates)["h_cz_p"]), eps, rng_seed=4,
+                               svd_options=options)
+    out, frame = alt.run(t.parse_to_mps([RefState.ZERO, RefState.PLUS], eps, qs))
+    arrays["run_alt_state"] = np.asarray(out.contract(), dtype=np.complex128)
+    cases["alt_frame"] = [list(p) for p in frame]
+    cases["runs"] = runs
+    cases["eps"] = eps
+    cases["options"] = options
+
+    # read-out operators on product code words
+    for n_modes, names in [(1, ["GKP_T"]), (2, ["GKP_H", "GKP_MINUS"])]:
+        mps = RefMPS(qs, [RefCVState[s].eval(qs, eps) for s in names])
+        arrays[f"rho_product_{n_modes}"] = np.asarray(u.full_logical_density_mps(mps), dtype=np.complex128)
+    save("gkp.npz", cases=json.dumps(cases), **arrays)
+
+
 if __name__ == "__main__":
     import logging
     logging.getLogger("simulators").setLevel(logging.ERROR)
@@ -452,6 +602,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--cv-mps-only" in sys.argv:
         gen_cv_mps()
+        sys.exit(0)
+    if "--gkp-only" in sys.argv:
+        gen_gkp()
         sys.exit(0)
     gen_single_gates()
     gen_expand_gate()
@@ -462,3 +615,4 @@ if __name__ == "__main__":
     gen_cv()
     gen_cv_extra()
     gen_cv_mps()
+    gen_gkp()

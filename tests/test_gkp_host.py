@@ -1,0 +1,118 @@
+"""Host logic of the measurement-based GKP layer against the reference's own outputs (tests/golden/gkp.npz), CPU only."""
+from __future__ import annotations
+
+import json
+
+import numpy as np
+import pytest
+
+from fixture_io import gkp_programs
+from quantum_computations_amd.dv_simulator import gates as DV
+from quantum_computations_amd.gkp_simulator import gates as G
+from quantum_computations_amd.gkp_simulator import simulator as S
+from quantum_computations_amd.gkp_simulator import transpiler as T
+from quantum_computations_amd.gkp_simulator import utils as U
+from quantum_computations_amd.gkp_simulator.insert_bell import GKPBellState, InsertBell
+
+
+@pytest.fixture(scope="module")
+def ref(golden):
+    g = golden["gkp"]
+    return g, json.loads(str(g["cases"]))
+
+
+def test_conversions_and_formatting(ref):
+    g, cases = ref
+    for eps, db in cases["eps2db"]:
+        assert abs(U.eps2db(eps) - db) < 1e-12
+    for db, eps in cases["db2eps"]:
+        assert abs(U.db2eps(db) - eps) < 1e-12
+        assert abs(U.eps2db(U.db2eps(db)) - db) < 1e-10
+    for value, text in cases["format_result"]:
+        assert U.format_result(value) == text
+    for value, bit in cases["cv2dv"]:
+        assert bool(U.cv2dv_information(value)) == bit
+    assert np.allclose(U.syndrome_matrix([(1, 0), (0, 1), (1, 1)]), g["syndrome_matrix"])
+
+
+def test_layering_matches_reference(ref):
+    _, cases = ref
+    for name, gates in gkp_programs(DV).items():
+        want = cases["layering"][name]
+        circuit = T.MBGKPCircuit.transpile(gates)
+        assert circuit.to_string() == want["text"], name
+        assert (circuit.depth(), circuit.count()) == (want["depth"], want["count"])
+        circuit.fill()
+        assert circuit.to_string() == want["filled"]
+        assert circuit.count() == want["filled_count"]
+
+
+def test_transpiler_rejects_what_the_reference_rejects():
+    circuit = T.MBGKPCircuit(3)
+    with pytest.raises(ValueError):
+        circuit.add_gate(DV.H(3))
+    with pytest.raises(ValueError):
+        circuit.add_gate(DV.CZ(0, 2))
+    with pytest.raises(ValueError):
+        circuit.add_gate(DV.CX(0, 1))
+    with pytest.raises(ValueError):
+        T.gate_transpile(DV.CX(0, 1))
+    with pytest.raises(TypeError):
+        T.parse_to_mps("zero", 0.3, np.linspace(-1, 1, 8))
+    assert T.state_transpile(T.DVState.TDG) is T.CVState.GKP_TDG
+
+
+def test_frame_commutation_table(ref):
+    _, cases = ref
+    make = {"I": lambda: DV.I(0), "T": lambda: DV.T(0), "Tdg": lambda: DV.Tdg(1), "H": lambda: DV.H(1),
+            "P": lambda: DV.P(0), "Pdg": lambda: DV.Pdg(1), "CZ": lambda: DV.CZ(0, 1), "SWAP": lambda: DV.SWAP(1, 0)}
+    for row in cases["commute"]:
+        frame, gate = S.commute(make[row["gate"]](), [tuple(p) for p in row["frame"]])
+        assert [list(p) for p in frame] == row["out"], row
+        assert repr(gate) == row["applied"], row
+    with pytest.raises(NotImplementedError):
+        S.commute(DV.X(0), [(0, 0)])
+
+
+def test_gadgets_compile_and_decode_like_the_reference(ref):
+    _, cases = ref
+    make = {"MBI": lambda: G.MBI(0), "MBF": lambda: G.MBF(0), "MBFdg": lambda: G.MBF(0, dagger=True),
+            "MBP": lambda: G.MBP(1), "MBPdg": lambda: G.MBP(1, dagger=True), "MBT": lambda: G.MBT(0),
+            "MBTdg": lambda: G.MBT(0, dagger=True), "MBCZ": lambda: G.MBCZ(0, 1), "MBSWAP": lambda: G.MBSWAP(2, 1)}
+    for row in cases["syndromes"]:
+        gadget = make[row["gadget"]]()
+        syndromes, indices = gadget.compute_syndrome(row["results"])
+        assert [list(s) for s in syndromes] == row["syndromes"], row
+        assert list(indices) == row["indices"]
+        assert [repr(c) for c in gadget.compile()] == row["compiled"], row["gadget"]
+        assert np.allclose(gadget.angles(), row["angles"])
+    with pytest.raises(ValueError):
+        G.MBCZ(0, 2)
+    with pytest.raises(ValueError):
+        G.MBF(0, results=(1.0,))
+    with pytest.raises(ValueError):
+        G.MBI(0).compute_syndrome([0.1])
+    assert G.GKPEC is G.MBI
+    assert isinstance(T.gate_transpile(DV.Tdg(1)), G.MBT) and T.gate_transpile(DV.Tdg(1)).dagger
+    assert not T.gate_transpile(DV.Pdg(0), dagger=True).dagger
+
+
+def test_bell_pair_halves(ref):
+    g, cases = ref
+    qs, eps = g["qs"], cases["eps"]
+    for name in ("PLUS", "T", "Tdg"):
+        first, second = GKPBellState[name].halves(qs, eps)
+        assert np.max(np.abs(first @ second - g[f"bell_{name}"])) < 1e-12
+    assert repr(GKPBellState.T) == "GKP_BELL_T"
+    with pytest.raises(TypeError):
+        InsertBell(0, "PLUS")
+    with pytest.raises(ValueError):
+        GKPBellState.PLUS.halves(qs, -0.1)
+
+
+def test_readout_operators_are_hermitian_and_bounded(ref):
+    g, _ = ref
+    ops = U.pauli_readout_operators(g["qs"])
+    for op in (ops[1], ops[3]):
+        assert np.allclose(op, op.conj().T)
+    assert np.allclose(ops[2], 1j * ops[1] @ ops[3])
