@@ -165,34 +165,51 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_mode2_gather(const amp_t *__restr
 // with wave-uniform (scalar) loads.  sum_b s_b^2 complex FMAs per plane instead of d^4 for the dense operator.
 constexpr int MAX_BLOCK = 32;
 
-__global__ __launch_bounds__(QSV_BLOCK) void k_mode2_blocks(amp_t *__restrict__ a, uint64_t L, int d, uint64_t Mid,
-                                                           uint64_t R, int nblocks,
-                                                           const int32_t *__restrict__ sizes,
-                                                           const int64_t *__restrict__ mat_start,  // in complex entries
-                                                           const int32_t *__restrict__ idx_start,
-                                                           const uint64_t *__restrict__ plane_off,  // amplitude offsets
-                                                           const double *__restrict__ mats) {
+// One work item = (plane, block): a thread loads the block's s amplitudes of its plane, multiplies by the block matrix
+// (wave-uniform scalar loads: the block index is the same for the whole workgroup) and stores them back.  Splitting the
+// planes' 2d-1 blocks over separate workgroups instead of walking them in one thread gives 2d-1 times more waves in
+// flight and short dependency chains.  Workgroup order: all blocks of one group of planes are dealt to the same XCD
+// back to back, so when the plane group is not contiguous in memory (R < 8: neighbouring lanes are up to 16 KiB apart and
+// every 128-byte line is shared by several anti-diagonals) the re-touched lines are served by that XCD's L2.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_mode2_blocks(amp_t *__restrict__ a, uint64_t L, int d, uint64_t Mid,
+                                                         uint64_t R, int nblocks, uint64_t groups,
+                                                         const int32_t *__restrict__ sizes,
+                                                         const int64_t *__restrict__ mat_start,  // in complex entries
+                                                         const int32_t *__restrict__ idx_start,
+                                                         const uint64_t *__restrict__ plane_off,  // amplitude offsets
+                                                         const double *__restrict__ mats) {
     const uint64_t planes = L * Mid * R;
-    for (uint64_t p = blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x; p < planes;
-         p += static_cast<uint64_t>(gridDim.x) * QSV_BLOCK) {
-    const uint64_t r = p % R, m = (p / R) % Mid, l = p / (R * Mid);
-    amp_t *base = a + l * (R * d * Mid * d) + m * (R * d) + r;
-    for (int b = 0; b < nblocks; ++b) {
+    const uint64_t items = (groups + 7) / 8 * 8 * nblocks;      // plane groups padded to a multiple of the 8 XCDs
+    for (uint64_t w = blockIdx.x; w < items; w += gridDim.x) {
+        // workgroup w runs on XCD w % 8; its sequence number there selects (group, block), block fastest
+        const uint64_t seq = w / 8;
+        const uint64_t g = (seq / nblocks) * 8 + w % 8;
+        const int b = static_cast<int>(seq % nblocks);
+        if (g >= groups) continue;
+        const uint64_t p = g * THREADS + threadIdx.x;
+        if (p >= planes) continue;
+        const uint64_t r = p % R, m = (p / R) % Mid, l = p / (R * Mid);
+        amp_t *base = a + l * (R * d * Mid * d) + m * (R * d) + r;
         const int s = sizes[b];
         const uint64_t *off = plane_off + idx_start[b];
         const double *M = mats + 2 * mat_start[b];
         amp_t x[MAX_BLOCK];
 #pragma unroll
-        for (int c = 0; c < MAX_BLOCK; ++c) x[c] = (c < s) ? base[off[c]] : amp_t{0.0, 0.0};
+        for (int c = 0; c < MAX_BLOCK; ++c) {
+            // contiguous plane groups touch every amplitude exactly once: stream past the caches
+            if (c < s) x[c] = THREADS == QSV_BLOCK ? __builtin_nontemporal_load(base + off[c]) : base[off[c]];
+            else x[c] = amp_t{0.0, 0.0};
+        }
         for (int row = 0; row < s; ++row) {
             const double *mr = M + 2 * static_cast<size_t>(row) * s;
             amp_t acc = {0.0, 0.0};
 #pragma unroll
             for (int c = 0; c < MAX_BLOCK; ++c)
                 if (c < s) acc = cfma(cplx{mr[2 * c], mr[2 * c + 1]}, x[c], acc);
-            base[off[row]] = acc;
+            if (THREADS == QSV_BLOCK) __builtin_nontemporal_store(acc, base + off[row]);
+            else base[off[row]] = acc;
         }
-    }
     }
 }
 
@@ -468,9 +485,19 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
     QSV_HIP(hipMemcpyAsync(d_i, idx_start.data(), sizeof(int32_t) * nblocks, hipMemcpyHostToDevice, st->stream));
     QSV_HIP(hipStreamSynchronize(st->stream));  // all sources are pageable host memory that dies at return
     const uint64_t planes = L * Mid * R;
-    const int grid = grid_of(planes, QSV_BLOCK, 0x00ffffff);
-    hipLaunchKernelGGL(k_mode2_blocks, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, L, static_cast<int>(d),
-                       Mid, R, nblocks, d_z, d_s, d_i, d_o, d_m);
+    // R >= 8: a 128-byte line holds amplitudes of one plane point only, so every line is touched by exactly one block
+    // (stream, nontemporal).  R < 8: lines are shared by up to 8 anti-diagonals; one wave per workgroup keeps a plane
+    // group (64 planes) small enough for the XCD's L2 to serve the re-touched lines.
+    const int threads = R >= 8 ? QSV_BLOCK : 64;
+    const uint64_t groups = (planes + threads - 1) / threads;
+    const uint64_t items = (groups + 7) / 8 * 8 * nblocks;
+    const unsigned grid = static_cast<unsigned>(items < 0x00ffffffull ? items : 0x00ffffffull);
+    if (threads == QSV_BLOCK)
+        hipLaunchKernelGGL(k_mode2_blocks<QSV_BLOCK>, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, L,
+                           static_cast<int>(d), Mid, R, nblocks, groups, d_z, d_s, d_i, d_o, d_m);
+    else
+        hipLaunchKernelGGL(k_mode2_blocks<64>, dim3(grid), dim3(64), 0, st->stream, st->data, L, static_cast<int>(d),
+                           Mid, R, nblocks, groups, d_z, d_s, d_i, d_o, d_m);
     return check_launch();
 }
 
