@@ -13,6 +13,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include <rocblas/rocblas.h>
@@ -173,6 +174,318 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_scale_strided(const amp_t *__rest
     }
 }
 
+// ----------------------------------------------------------------------------------------------------
+// Fused tall-skinny kernels for the randomized split.  rocSOLVER's zgeqrf / zungqr / zgesvd on an (n x l) panel with
+// l = k + 10 <= 64 columns are hundreds of microsecond-sized launches each (profiles/r01_mps_kernel_stats.csv: half of
+// the GPU time of a split), and the range finder re-orthonormalises 15 times.  Any orthonormal basis of the same
+// subspace gives the same U S Vh, so the panels are orthonormalised by shifted CholeskyQR3 (Fukaya et al., SIAM J.
+// Sci. Comput. 42, 2020): three rounds of  G = Y^H Y,  R = chol(G + shift I),  Y <- Y R^-1  -- three launches per
+// round, every one a single pass over the panel; the shift of the first round makes the factorisation succeed for
+// condition numbers up to 1/u, directions that are numerically absent are detected by their pivot in the later
+// rounds and dropped (zero columns; Householder QR would invent arbitrary complements there).  The (l x m) projection
+// B is never decomposed directly either: B^H is orthonormalised the same way (B^H = Qb Rb) and the l x l triangle Rb
+// goes through a one-sided Jacobi SVD in a single workgroup (high relative accuracy, no bidiagonalisation).
+// ----------------------------------------------------------------------------------------------------
+constexpr int LMAX = 64;            // widest panel the fused kernels take
+constexpr int PANEL_ROWS = 64;      // rows per LDS tile
+constexpr int PANEL_PITCH = PANEL_ROWS + 1;
+constexpr int GRAM_BLOCKS = 256;
+
+__device__ __forceinline__ amp_t conj_mul(amp_t a, amp_t b) {   // conj(a) * b
+    return amp_t{a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ amp_t plain_mul(amp_t a, amp_t b) {
+    return amp_t{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+
+// partials[block][i * l + j] = sum over the block's rows of conj(Y[r, i]) * Y[r, j]   (Y column-major, ld n)
+__global__ __launch_bounds__(256) void k_panel_gram(const amp_t *__restrict__ Y, uint64_t n, int l,
+                                                   amp_t *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    amp_t *tile = reinterpret_cast<amp_t *>(smem_raw);   // [l][PANEL_PITCH]
+    const int t = threadIdx.x, entries = l * l;
+    amp_t acc[LMAX * LMAX / 256];
+#pragma unroll
+    for (int k = 0; k < LMAX * LMAX / 256; ++k) acc[k] = amp_t{0.0, 0.0};
+    for (uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * PANEL_ROWS; r0 < n;
+         r0 += static_cast<uint64_t>(gridDim.x) * PANEL_ROWS) {
+        __syncthreads();
+        for (int idx = t; idx < l * PANEL_ROWS; idx += 256) {
+            const int c = idx / PANEL_ROWS, r = idx % PANEL_ROWS;
+            tile[c * PANEL_PITCH + r] = r0 + r < n ? Y[static_cast<uint64_t>(c) * n + r0 + r] : amp_t{0.0, 0.0};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LMAX * LMAX / 256; ++k) {
+            const int e = t + 256 * k;
+            if (e < entries) {
+                const amp_t *ci = tile + (e / l) * PANEL_PITCH, *cj = tile + (e % l) * PANEL_PITCH;
+                amp_t a = acc[k];
+                for (int r = 0; r < PANEL_ROWS; ++r) {
+                    const amp_t p = conj_mul(ci[r], cj[r]);
+                    a.x += p.x;
+                    a.y += p.y;
+                }
+                acc[k] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LMAX * LMAX / 256; ++k) {
+        const int e = t + 256 * k;
+        if (e < entries) partials[static_cast<size_t>(blockIdx.x) * entries + e] = acc[k];
+    }
+}
+
+// One workgroup: G = sum of the partials (+ shift), upper Cholesky factor R with G = R^H R, its inverse, and the running
+// product r_total = R * r_prev.  first_round != 0 applies the CholeskyQR3 shift; otherwise pivots at rounding level
+// mark absent directions: their column of R^-1 is zeroed (the panel column becomes zero).
+__global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ partials, int nblocks, int l,
+                                                     uint64_t rows, int first_round,
+                                                     const amp_t *__restrict__ r_prev, amp_t *__restrict__ r_total,
+                                                     amp_t *__restrict__ r_inv) {
+    __shared__ amp_t G[LMAX * LMAX];
+    __shared__ amp_t Inv[LMAX * LMAX];
+    __shared__ double pivot_floor, shift;
+    __shared__ int absent[LMAX];
+    const int t = threadIdx.x, entries = l * l;
+    for (int e = t; e < entries; e += 256) {
+        amp_t s = {0.0, 0.0};
+        for (int b = 0; b < nblocks; ++b) {
+            const amp_t v = partials[static_cast<size_t>(b) * entries + e];
+            s.x += v.x;
+            s.y += v.y;
+        }
+        G[e] = s;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double trace = 0.0, top = 0.0;
+        for (int j = 0; j < l; ++j) {
+            trace += G[j * l + j].x;
+            top = fmax(top, G[j * l + j].x);
+        }
+        const double u = 1.1102230246251565e-16;
+        shift = first_round ? 11.0 * (static_cast<double>(rows) * l + static_cast<double>(l) * (l + 1)) * u * trace : 0.0;
+        pivot_floor = first_round ? 0.0 : static_cast<double>(l) * u * top;
+    }
+    __syncthreads();
+    for (int j = 0; j < l; ++j) {
+        __syncthreads();
+        const double pivot = G[j * l + j].x + shift;
+        const bool gone = !(pivot > pivot_floor);
+        const double rjj = gone ? 1.0 : sqrt(pivot);
+        __syncthreads();
+        if (t == 0) {
+            G[j * l + j] = amp_t{rjj, 0.0};
+            absent[j] = gone;
+        }
+        for (int k = j + 1 + t; k < l; k += 256) {
+            amp_t v = G[j * l + k];
+            G[j * l + k] = gone ? amp_t{0.0, 0.0} : amp_t{v.x / rjj, v.y / rjj};
+        }
+        __syncthreads();
+        // trailing update G[i][k] -= conj(R[j][i]) * R[j][k] for j < i <= k
+        const int width = l - j - 1;
+        for (int e = t; e < width * width; e += 256) {
+            const int i = j + 1 + e / width, k = j + 1 + e % width;
+            if (k >= i) {
+                const amp_t p = conj_mul(G[j * l + i], G[j * l + k]);
+                G[i * l + k].x -= p.x;
+                G[i * l + k].y -= p.y;
+            }
+        }
+    }
+    __syncthreads();
+    // R^-1 by back substitution, one column per thread
+    for (int c = t; c < l; c += 256) {
+        for (int i = 0; i < l; ++i) Inv[i * l + c] = amp_t{0.0, 0.0};
+        if (!absent[c]) {
+            Inv[c * l + c] = amp_t{1.0 / G[c * l + c].x, 0.0};
+            for (int i = c - 1; i >= 0; --i) {
+                amp_t sum = {0.0, 0.0};
+                for (int k = i + 1; k <= c; ++k) {
+                    const amp_t p = plain_mul(G[i * l + k], Inv[k * l + c]);
+                    sum.x += p.x;
+                    sum.y += p.y;
+                }
+                const double d = G[i * l + i].x;
+                Inv[i * l + c] = amp_t{-sum.x / d, -sum.y / d};
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < entries; e += 256) {
+        r_inv[e] = Inv[e];
+        if (r_total) {
+            const int i = e / l, k = e % l;
+            amp_t sum = {0.0, 0.0};
+            if (absent[i]) {
+                // the panel column of an absent direction is zero: its row of the factor must not reach the SVD
+            } else if (r_prev) {
+                for (int q = i; q <= k; ++q) {   // both factors are upper triangular
+                    const amp_t p = plain_mul(G[i * l + q], r_prev[q * l + k]);
+                    sum.x += p.x;
+                    sum.y += p.y;
+                }
+            } else if (k >= i) {
+                sum = G[e];
+            }
+            Inv[e] = sum;   // staged: r_total may alias r_prev
+        }
+    }
+    __syncthreads();
+    if (r_total)
+        for (int e = t; e < entries; e += 256) r_total[e] = Inv[e];
+}
+
+// Y <- Y * r_inv (upper triangular, row-major [i * l + j]) in place, one 64-row tile per pass
+__global__ __launch_bounds__(256) void k_panel_apply(amp_t *__restrict__ Y, uint64_t n, int l,
+                                                    const amp_t *__restrict__ r_inv) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    amp_t *tile = reinterpret_cast<amp_t *>(smem_raw);   // [l][PANEL_PITCH]
+    const int t = threadIdx.x, r = t % PANEL_ROWS, lane_group = t / PANEL_ROWS;
+    for (uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * PANEL_ROWS; r0 < n;
+         r0 += static_cast<uint64_t>(gridDim.x) * PANEL_ROWS) {
+        __syncthreads();
+        for (int idx = t; idx < l * PANEL_ROWS; idx += 256) {
+            const int c = idx / PANEL_ROWS, rr = idx % PANEL_ROWS;
+            tile[c * PANEL_PITCH + rr] = r0 + rr < n ? Y[static_cast<uint64_t>(c) * n + r0 + rr] : amp_t{0.0, 0.0};
+        }
+        __syncthreads();
+        for (int j = lane_group; j < l; j += 256 / PANEL_ROWS) {   // j is wave-uniform: r_inv comes through scalar loads
+            amp_t acc = {0.0, 0.0};
+            for (int i = 0; i <= j; ++i) {
+                const amp_t p = plain_mul(tile[i * PANEL_PITCH + r], r_inv[i * l + j]);
+                acc.x += p.x;
+                acc.y += p.y;
+            }
+            if (r0 + r < n) Y[static_cast<uint64_t>(j) * n + r0 + r] = acc;
+        }
+    }
+}
+
+// SVD of the l x l matrix R (row-major) by one-sided Jacobi in one workgroup: R V = U S.  Column pairs follow a
+// round-robin tournament (l/2 disjoint pairs per step, a few threads per pair); outputs are sorted by decreasing
+// singular value: U, V column-major (l x l), S (l doubles).
+__global__ __launch_bounds__(256) void k_small_svd(const amp_t *__restrict__ R, int l, amp_t *__restrict__ U,
+                                                  double *__restrict__ S, amp_t *__restrict__ V) {
+    __shared__ amp_t W[LMAX * LMAX];    // working columns, column-major
+    __shared__ amp_t Vw[LMAX * LMAX];
+    __shared__ double sigma[LMAX];
+    __shared__ int order[LMAX];
+    __shared__ int rotated;
+    const int t = threadIdx.x;
+    for (int e = t; e < l * l; e += 256) {
+        const int c = e / l, r = e % l;
+        W[c * l + r] = R[r * l + c];
+        Vw[c * l + r] = amp_t{r == c ? 1.0 : 0.0, 0.0};
+    }
+    const int lp = (l + 1) & ~1, pairs = lp / 2;
+    int team = 1;                       // threads per pair: a power of two, pairs * team <= 256, team <= 64
+    while (team * 2 * pairs <= 256 && team < 64) team *= 2;
+    const int pair = t / team, member = t % team;
+    const double eps = 2.220446049250313e-16;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        __syncthreads();
+        if (t == 0) rotated = 0;
+        for (int step = 0; step < lp - 1; ++step) {
+            __syncthreads();
+            int p = -1, q = -1;
+            if (pair < pairs) {
+                if (pair == 0) {
+                    p = lp - 1;
+                    q = step;
+                } else {
+                    p = (step + pair) % (lp - 1);
+                    q = (step - pair + (lp - 1)) % (lp - 1);
+                }
+                if (p > q) {
+                    const int tmp = p;
+                    p = q;
+                    q = tmp;
+                }
+            }
+            const bool live = pair < pairs && q < l;     // the padding column of an odd l sits out
+            double alpha = 0.0, beta = 0.0;
+            amp_t gamma = {0.0, 0.0};
+            if (live) {
+                for (int r = member; r < l; r += team) {
+                    const amp_t x = W[p * l + r], y = W[q * l + r];
+                    alpha += x.x * x.x + x.y * x.y;
+                    beta += y.x * y.x + y.y * y.y;
+                    const amp_t g = conj_mul(x, y);
+                    gamma.x += g.x;
+                    gamma.y += g.y;
+                }
+            }
+            for (int o = team / 2; o > 0; o >>= 1) {     // teams are aligned sub-groups of a wave
+                alpha += __shfl_xor(alpha, o, 64);
+                beta += __shfl_xor(beta, o, 64);
+                gamma.x += __shfl_xor(gamma.x, o, 64);
+                gamma.y += __shfl_xor(gamma.y, o, 64);
+            }
+            const double g2 = gamma.x * gamma.x + gamma.y * gamma.y;
+            if (live && g2 > eps * eps * alpha * beta && g2 > 0.0) {
+                const double g = sqrt(g2);
+                const amp_t phase = {gamma.x / g, -gamma.y / g};          // conj(gamma / |gamma|)
+                const double zeta = (beta - alpha) / (2.0 * g);
+                const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + tt * tt), sn = c * tt;
+                for (int r = member; r < l; r += team) {
+                    const amp_t x = W[p * l + r], y = plain_mul(W[q * l + r], phase);
+                    W[p * l + r] = amp_t{c * x.x - sn * y.x, c * x.y - sn * y.y};
+                    W[q * l + r] = amp_t{sn * x.x + c * y.x, sn * x.y + c * y.y};
+                    const amp_t vx = Vw[p * l + r], vy = plain_mul(Vw[q * l + r], phase);
+                    Vw[p * l + r] = amp_t{c * vx.x - sn * vy.x, c * vx.y - sn * vy.y};
+                    Vw[q * l + r] = amp_t{sn * vx.x + c * vy.x, sn * vx.y + c * vy.y};
+                }
+                if (member == 0) rotated = 1;
+            }
+        }
+        __syncthreads();
+        if (!rotated) break;
+    }
+    __syncthreads();
+    for (int c = t; c < l; c += 256) {
+        double s = 0.0;
+        for (int r = 0; r < l; ++r) s += W[c * l + r].x * W[c * l + r].x + W[c * l + r].y * W[c * l + r].y;
+        sigma[c] = sqrt(s);
+    }
+    __syncthreads();
+    if (t == 0) {                       // ranks by decreasing singular value (l <= 64)
+        for (int c = 0; c < l; ++c) {
+            int rank = 0;
+            for (int o = 0; o < l; ++o) rank += sigma[o] > sigma[c] || (sigma[o] == sigma[c] && o < c);
+            order[rank] = c;
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < l * l; e += 256) {
+        const int rank = e / l, r = e % l, c = order[rank];
+        const double s = sigma[c];
+        const amp_t w = W[c * l + r];
+        U[rank * l + r] = s > 0.0 ? amp_t{w.x / s, w.y / s} : amp_t{0.0, 0.0};
+        V[rank * l + r] = Vw[c * l + r];
+    }
+    for (int rank = t; rank < l; rank += 256) S[rank] = sigma[order[rank]];
+}
+
+// out[a, b] (row-major A x B) = sqrt(s[by_row ? a : b]) * (conj ? conj(in[...]) : in[a * sa + b * sb])
+__global__ __launch_bounds__(QSV_BLOCK) void k_scale_strided_conj(const amp_t *__restrict__ in, amp_t *__restrict__ out,
+                                                                 uint64_t A, uint64_t B, uint64_t sa, uint64_t sb,
+                                                                 const double *__restrict__ s, int by_row,
+                                                                 int conjugate) {
+    const uint64_t total = A * B;
+    for (uint64_t o = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; o < total;
+         o += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t a = o / B, b = o % B;
+        const double w = sqrt(s[by_row ? a : b]);
+        const amp_t v = in[a * sa + b * sb];
+        out[o] = amp_t{w * v.x, conjugate ? -w * v.y : w * v.y};
+    }
+}
+
 // The reference's truncation rule (mps.py:83-86) on singular values sorted in decreasing order.
 uint64_t kept_rank(const std::vector<double> &sv, int64_t max_bond_dim, double abs_err, double rel_err) {
     double total = 0.0;
@@ -269,6 +582,121 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
     return QSV_OK;
 }
 
+// Shifted CholeskyQR3 of the column-major (n x l) panel Y, in place.  `r_total` (l x l, row-major, may be null) receives
+// the triangular factor with  Y_in = Y_out * r_total.
+int panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t *partials, amp_t *r_inv,
+                         amp_t *r_total) {
+    const size_t lds = sizeof(amp_t) * l * PANEL_PITCH;
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_panel_gram),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LMAX * PANEL_PITCH * sizeof(amp_t))));
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_panel_apply),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LMAX * PANEL_PITCH * sizeof(amp_t))));
+        raised = true;
+    }
+    const uint64_t tiles = (n + PANEL_ROWS - 1) / PANEL_ROWS;
+    const int gram_blocks = static_cast<int>(tiles < GRAM_BLOCKS ? tiles : GRAM_BLOCKS);
+    const unsigned apply_blocks = static_cast<unsigned>(tiles < 4096 ? tiles : 4096);
+    for (int round = 0; round < 3; ++round) {
+        hipLaunchKernelGGL(k_panel_gram, dim3(gram_blocks), dim3(256), lds, stream, Y, n, l, partials);
+        hipLaunchKernelGGL(k_panel_factor, dim3(1), dim3(256), 0, stream, partials, gram_blocks, l, n, round == 0,
+                           round == 0 ? nullptr : r_total, r_total, r_inv);
+        hipLaunchKernelGGL(k_panel_apply, dim3(apply_blocks), dim3(256), lds, stream, Y, n, l, r_inv);
+    }
+    QSV_HIP(hipGetLastError());
+    return QSV_OK;
+}
+
+bool fused_panels_enabled() {
+    static const bool on = [] {
+        const char *v = std::getenv("QSV_RSVD");
+        return !(v && std::string(v) == "rocsolver");
+    }();
+    return on;
+}
+
+// The randomized split with the fused panel kernels: same algorithm and random stream as below, but every
+// re-orthonormalisation is 9 launches and the l x m projection is decomposed through B^H = Qb Rb and a Jacobi SVD of Rb.
+int rsvd_split_fused(RocblasApi &a, rocblas_handle h, hipStream_t stream, const amp_t *theta, uint64_t rows,
+                     uint64_t cols, int64_t k_keep, int l, int q, const amp_t *omega, double abs_err, double rel_err,
+                     amp_t *m1, amp_t *m2, uint64_t capacity, uint64_t *rank_out, double *s_host) {
+    const bool wide = rows < cols;
+    const uint64_t n = wide ? cols : rows, m = wide ? rows : cols;
+    const uint64_t L = static_cast<uint64_t>(l);
+    DeviceBuffers buf;
+    amp_t *A = nullptr, *Qn = nullptr, *Qm = nullptr, *partials = nullptr, *small = nullptr, *UA = nullptr, *VA = nullptr;
+    double *dS = nullptr;
+    // small: r_inv | r_total | U_r | V_r, each L x L
+    if (!buf.alloc(&Qn, sizeof(amp_t) * n * L) || !buf.alloc(&Qm, sizeof(amp_t) * m * L) ||
+        !buf.alloc(&partials, sizeof(amp_t) * GRAM_BLOCKS * L * L) || !buf.alloc(&small, sizeof(amp_t) * 4 * L * L) ||
+        !buf.alloc(&dS, sizeof(double) * L))
+        return qsv_fail(QSV_ENOMEM, "device allocation of the randomized-SVD workspace failed");
+    amp_t *r_inv = small, *r_total = small + L * L, *Ur = small + 2 * L * L, *Vr = small + 3 * L * L;
+    if (wide) {
+        A = const_cast<amp_t *>(theta);      // row-major (rows x cols) read column-major is theta^T = A
+    } else {
+        if (!buf.alloc(&A, sizeof(amp_t) * n * m))
+            return qsv_fail(QSV_ENOMEM, "device allocation of the randomized-SVD workspace failed");
+        const uint64_t tiles = ((n + 15) / 16) * ((m + 15) / 16);
+        hipLaunchKernelGGL(k_to_column_major, dim3(static_cast<unsigned>(tiles < 65536 ? tiles : 65536)), dim3(256), 0,
+                           stream, theta, A, n, m);
+        QSV_HIP(hipGetLastError());
+    }
+    const rocblas_double_complex one{1.0, 0.0}, zero{0.0, 0.0};
+    auto Z = [](const amp_t *p) { return reinterpret_cast<const rocblas_double_complex *>(p); };
+    auto W = [](amp_t *p) { return reinterpret_cast<rocblas_double_complex *>(p); };
+    const rocblas_int ni = static_cast<rocblas_int>(n), mi = static_cast<rocblas_int>(m), li = static_cast<rocblas_int>(L);
+    auto gemm = [&](rocblas_operation ta, rocblas_operation tb, rocblas_int M_, rocblas_int N_, rocblas_int K_,
+                    const amp_t *pa, rocblas_int lda, const amp_t *pb, rocblas_int ldb, amp_t *pc, rocblas_int ldc) {
+        return a.zgemm(h, ta, tb, M_, N_, K_, &one, Z(pa), lda, 0, Z(pb), ldb, 0, &zero, W(pc), ldc, 0, 1) ==
+               rocblas_status_success;
+    };
+    const rocblas_operation N = rocblas_operation_none, Cc = rocblas_operation_conjugate_transpose;
+    bool ok = gemm(N, N, ni, li, mi, A, ni, omega, mi, Qn, ni);                                   // Y = A O
+    int rc = ok ? panel_orthonormalise(stream, Qn, n, l, partials, r_inv, nullptr) : QSV_OK;
+    for (int it = 0; ok && !rc && it < q; ++it) {
+        ok = gemm(Cc, N, mi, li, ni, A, ni, Qn, ni, Qm, mi);                                      // Y = A^H Q
+        if (ok) rc = panel_orthonormalise(stream, Qm, m, l, partials, r_inv, nullptr);
+        ok = ok && !rc && gemm(N, N, ni, li, mi, A, ni, Qm, mi, Qn, ni);                          // Y = A Q
+        if (ok) rc = panel_orthonormalise(stream, Qn, n, l, partials, r_inv, nullptr);
+    }
+    // B^H = A^H Q = Qb Rb  (m x l);  Rb = Ur S Vr^H;  A ~ (Q Vr) S (Qb Ur)^H
+    ok = ok && !rc && gemm(Cc, N, mi, li, ni, A, ni, Qn, ni, Qm, mi);
+    if (ok) rc = panel_orthonormalise(stream, Qm, m, l, partials, r_inv, r_total);
+    if (!ok) return qsv_fail(QSV_EHIP, "rocBLAS call failed in the randomized range finder");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_small_svd, dim3(1), dim3(256), 0, stream, r_total, l, Ur, dS, Vr);
+    QSV_HIP(hipGetLastError());
+    const uint64_t k = static_cast<uint64_t>(k_keep);
+    std::vector<double> sv(k);
+    QSV_HIP(hipMemcpyAsync(sv.data(), dS, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+    QSV_HIP(hipStreamSynchronize(stream));
+    const uint64_t r = kept_rank(sv, k_keep, abs_err, rel_err);
+    if (r > capacity) return qsv_fail(QSV_EINVAL, "output buffers are smaller than the kept bond dimension");
+    if (r > 0) {
+        const rocblas_int ri = static_cast<rocblas_int>(r);
+        if (!buf.alloc(&UA, sizeof(amp_t) * n * r) || !buf.alloc(&VA, sizeof(amp_t) * m * r))
+            return qsv_fail(QSV_ENOMEM, "device allocation of the randomized-SVD workspace failed");
+        if (!gemm(N, N, ni, ri, li, Qn, ni, Vr, li, UA, ni) || !gemm(N, N, mi, ri, li, Qm, mi, Ur, li, VA, mi))
+            return qsv_fail(QSV_EHIP, "rocblas_zgemm failed");
+        // A = UA S VA^H.  Tall theta = A:  m1 = UA sqrt(S),  m2 = sqrt(S) VA^H.
+        // Wide theta = A^T = conj(VA) S UA^T:  m1 = conj(VA) sqrt(S),  m2 = sqrt(S) UA^T.
+        const amp_t *u_src = wide ? VA : UA, *v_src = wide ? UA : VA;
+        const uint64_t u_ld = wide ? m : n, v_ld = wide ? n : m;
+        hipLaunchKernelGGL(k_scale_strided_conj, dim3(blocks_for(rows * r)), dim3(QSV_BLOCK), 0, stream, u_src, m1, rows,
+                           r, static_cast<uint64_t>(1), u_ld, dS, 0, wide ? 1 : 0);
+        hipLaunchKernelGGL(k_scale_strided_conj, dim3(blocks_for(r * cols)), dim3(QSV_BLOCK), 0, stream, v_src, m2, r,
+                           cols, v_ld, static_cast<uint64_t>(1), dS, 1, wide ? 0 : 1);
+        QSV_HIP(hipGetLastError());
+    }
+    QSV_HIP(hipStreamSynchronize(stream));   // the workspace is freed on return
+    if (s_host)
+        for (uint64_t i = 0; i < k; ++i) s_host[i] = sv[i];
+    *rank_out = r;
+    return QSV_OK;
+}
+
 // tensor_svd on its randomized branch (mps.py:5-50,78-79; Halko, Martinsson & Tropp 2010): range finder with
 // l = k + 10 Gaussian probes (drawn by the caller so that the reference's random stream is reproduced) and q power
 // iterations re-orthonormalised by Householder QR, SVD of the small l x m' projection, first k triplets kept, then the
@@ -291,6 +719,9 @@ int qsvg_rsvd_split(int device, hipStream_t stream, const amp_t *theta, uint64_t
     const uint64_t L = static_cast<uint64_t>(l), kk = L < m ? L : m;
     if (k_keep < 1 || L < static_cast<uint64_t>(k_keep) || L > m)
         return qsv_fail(QSV_EINVAL, "need 1 <= k <= l <= min(rows, cols)");
+    if (L <= LMAX && fused_panels_enabled())
+        return rsvd_split_fused(a, h, stream, theta, rows, cols, k_keep, l, q, omega, abs_err, rel_err, m1, m2, capacity,
+                                rank_out, s_host);
     DeviceBuffers buf;
     amp_t *A = nullptr, *Qn = nullptr, *Qm = nullptr, *tau = nullptr, *B = nullptr, *UB = nullptr, *VB = nullptr;
     double *dS = nullptr, *dE = nullptr;
