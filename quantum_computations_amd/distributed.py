@@ -385,8 +385,30 @@ class ShardedState:
             self.local.apply_matrix(u, [self._local_qubit(tb)])
         return self
 
-    def insert(self, index: int, amplitudes):
-        raise NotImplementedError("Insert on a sharded register is not built yet: start from ShardedState.zeros")
+    def insert(self, index: int, amplitudes) -> "ShardedState":
+        """``Insert.apply`` (gates.py:145-153) on the sharded register: the new qubit (a product factor
+        ``amplitudes = (a0, a1)``) becomes reference qubit ``index``.  It is made the *least significant local* qubit,
+        so no amplitude crosses a link: every shard doubles in place (a new buffer of twice the size, the local engine
+        interleaves the two scaled copies) and only the logical->physical map records where the qubit belongs."""
+        import torch
+
+        if index < 0 or index > self.n:
+            raise ValueError("new_ordering must be a permutation of all qubits")
+        self.local.sync()
+        old_amps = 1 << self.n_local
+        grown = torch.empty(2 * old_amps, dtype=self.buf.dtype, device=self.buf.device)
+        grown[:old_amps].copy_(self.buf[:old_amps])
+        self.buf = grown
+        self.local = self._factory(grown, self.n_local)       # same n_local qubits, room for one more
+        self.local.insert(self.n_local, amplitudes)            # local reference position n_local = physical bit 0
+        new_logical_bit = self.n - index                       # bit of the new qubit in the (n+1)-qubit register
+        self.phys = [p + 1 for p in self.phys]
+        self.phys.insert(new_logical_bit, 0)
+        self.n += 1
+        self.n_local += 1
+        self._scratch = None                                   # half-shard buffers have the wrong size now
+        self._plan = None
+        return self
 
     # ---- measurement ----------------------------------------------------------------------------
     def measure_probs(self, index: int, eig0, eig1) -> tuple[float, float]:

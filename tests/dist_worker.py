@@ -169,6 +169,26 @@ def main():
     assert out.num_qubits == n - 2
     check("measurement", out.to_numpy(), want)
 
+    # 3a. insertion: the new qubit lands on a local bit, wherever the reference order puts it
+    ket = W.random_ket(n, 6)
+    st = make_state(n, ket, args.backend, device)
+    G.H(0).apply(st)
+    want = O.apply_gate(ket, G.H(0).matrix, [0])
+    before = st.exchanges
+    for position, amplitudes in [(0, [0.6, 0.8j]), (st.num_qubits + 1, [1.0, 0.0]), (3, [2 ** -0.5, -(2 ** -0.5)])]:
+        st.insert(position, amplitudes)
+        want = O.insert_qubit(want, position, np.array(amplitudes, dtype=complex))
+    assert st.exchanges == before, "inserting a product qubit must not communicate"
+    assert st.num_qubits == n + 3
+    check("insert", st.to_numpy(), want)
+    G.CX(0, st.num_qubits - 1).apply(st)             # the grown register keeps working, remote qubits included
+    G.H(3).apply(st)
+    want = O.apply_gate(want, W.op("CX", 0, 1)["matrix"], [0, n + 2])
+    want = O.apply_gate(want, G.H(0).matrix, [3])
+    check("gates after insert", st.to_numpy(), want)
+    with np.testing.assert_raises(ValueError):
+        st.insert(st.num_qubits + 1, [1, 0])
+
     # 3b. BASELINE config 5 in small: Grover search on the sharded register, success probability vs the analytic value
     marked = (0b1011001110 >> max(0, 10 - n)) | 1
     start = np.zeros(1 << n, dtype=complex)

@@ -98,6 +98,12 @@ class OracleEngine:
         self._store(out)
         return self
 
+    def insert(self, index: int, amplitudes):
+        grown = O.insert_qubit(self.arr.copy(), index, np.asarray(amplitudes))
+        self.n += 1
+        self._store(grown)
+        return self
+
     def norm2(self) -> float:
         return float(np.sum(np.abs(self.arr) ** 2))
 
