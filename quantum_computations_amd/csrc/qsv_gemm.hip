@@ -131,17 +131,57 @@ int blocks_for(uint64_t items) {
     return static_cast<int>(b < 1 ? 1 : (b > 65536 ? 65536 : b));
 }
 
-struct DeviceBuffers {   // frees whatever was allocated when it goes out of scope
-    void *p[12] = {};
+// Scratch memory of the decompositions: one grow-only pool per device (a split needs a copy of theta plus panels --
+// gigabytes -- and hipMalloc / hipFree of that size on every call costs milliseconds and synchronises the device).
+// A DeviceBuffers object carves from the pool; requests the pool cannot hold fall back to hipMalloc and are freed when
+// the object goes out of scope.  Calls are serialised by the library lock and end with a stream synchronisation, so the
+// pool is never in use by two calls.
+struct Pool {
+    char *base = nullptr;
+    size_t capacity = 0;
+};
+
+Pool &pool_of(int device) {
+    static Pool pools[16];
+    return pools[device];
+}
+
+struct DeviceBuffers {
+    Pool *pool = nullptr;
+    size_t used = 0;
+    void *extra[12] = {};
     int n = 0;
+
+    // Make the pool of `device` at least `bytes` large (no-op when it already is).  Call before the first alloc.
+    void reserve(int device, size_t bytes) {
+        pool = &pool_of(device);
+        if (pool->capacity >= bytes) return;
+        if (pool->base) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(pool->base);
+            pool->base = nullptr;
+            pool->capacity = 0;
+        }
+        const size_t want = bytes + bytes / 8;
+        if (hipMalloc(reinterpret_cast<void **>(&pool->base), want) == hipSuccess) pool->capacity = want;
+        else pool->base = nullptr;
+    }
+
     template <class T>
     bool alloc(T **out, size_t bytes) {
-        if (hipMalloc(reinterpret_cast<void **>(out), bytes ? bytes : 16) != hipSuccess) return false;
-        p[n++] = *out;
+        const size_t need = (bytes + 255) / 256 * 256;
+        if (pool && pool->base && used + need <= pool->capacity) {
+            *out = reinterpret_cast<T *>(pool->base + used);
+            used += need;
+            return true;
+        }
+        if (n >= 12 || hipMalloc(reinterpret_cast<void **>(out), bytes ? bytes : 16) != hipSuccess) return false;
+        extra[n++] = *out;
         return true;
     }
+
     ~DeviceBuffers() {
-        for (int i = 0; i < n; ++i) (void)hipFree(p[i]);
+        for (int i = 0; i < n; ++i) (void)hipFree(extra[i]);
     }
 };
 
@@ -189,7 +229,7 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_scale_strided(const amp_t *__rest
 constexpr int LMAX = 64;            // widest panel the fused kernels take
 constexpr int PANEL_ROWS = 64;      // rows per LDS tile
 constexpr int PANEL_PITCH = PANEL_ROWS + 1;
-constexpr int GRAM_BLOCKS = 256;
+constexpr int GRAM_BLOCKS = 64;     // partial Gram matrices per panel (summed by one workgroup: keep it short)
 
 __device__ __forceinline__ amp_t conj_mul(amp_t a, amp_t b) {   // conj(a) * b
     return amp_t{a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x};
@@ -251,7 +291,18 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
     const int t = threadIdx.x, entries = l * l;
     for (int e = t; e < entries; e += 256) {
         amp_t s = {0.0, 0.0};
-        for (int b = 0; b < nblocks; ++b) {
+        int b = 0;
+        for (; b + 8 <= nblocks; b += 8) {          // eight independent loads in flight, summed in block order
+            amp_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partials[static_cast<size_t>(b + k) * entries + e];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                s.x += v[k].x;
+                s.y += v[k].y;
+            }
+        }
+        for (; b < nblocks; ++b) {
             const amp_t v = partials[static_cast<size_t>(b) * entries + e];
             s.x += v.x;
             s.y += v.y;
@@ -547,6 +598,7 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
     if (!a.zgesvd) return qsv_fail(QSV_EHIP, "rocSOLVER could not be loaded (librocsolver.so.0): no SVD available");
     const uint64_t k = rows < cols ? rows : cols;
     DeviceBuffers buf;
+    buf.reserve(device, sizeof(amp_t) * (cols * k + k * rows) + 16 * k + 4096);
     double *dS = nullptr, *dE = nullptr;
     amp_t *dU = nullptr, *dV = nullptr;
     rocblas_int *dinfo = nullptr;
@@ -618,13 +670,15 @@ bool fused_panels_enabled() {
 
 // The randomized split with the fused panel kernels: same algorithm and random stream as below, but every
 // re-orthonormalisation is 9 launches and the l x m projection is decomposed through B^H = Qb Rb and a Jacobi SVD of Rb.
-int rsvd_split_fused(RocblasApi &a, rocblas_handle h, hipStream_t stream, const amp_t *theta, uint64_t rows,
+int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t stream, const amp_t *theta, uint64_t rows,
                      uint64_t cols, int64_t k_keep, int l, int q, const amp_t *omega, double abs_err, double rel_err,
                      amp_t *m1, amp_t *m2, uint64_t capacity, uint64_t *rank_out, double *s_host) {
     const bool wide = rows < cols;
     const uint64_t n = wide ? cols : rows, m = wide ? rows : cols;
     const uint64_t L = static_cast<uint64_t>(l);
     DeviceBuffers buf;
+    buf.reserve(device, sizeof(amp_t) * ((n + m) * (L + static_cast<uint64_t>(k_keep)) + (GRAM_BLOCKS + 4) * L * L +
+                                         (wide ? 0 : n * m)) + 8 * L + 8192);
     amp_t *A = nullptr, *Qn = nullptr, *Qm = nullptr, *partials = nullptr, *small = nullptr, *UA = nullptr, *VA = nullptr;
     double *dS = nullptr;
     // small: r_inv | r_total | U_r | V_r, each L x L
@@ -720,9 +774,11 @@ int qsvg_rsvd_split(int device, hipStream_t stream, const amp_t *theta, uint64_t
     if (k_keep < 1 || L < static_cast<uint64_t>(k_keep) || L > m)
         return qsv_fail(QSV_EINVAL, "need 1 <= k <= l <= min(rows, cols)");
     if (L <= LMAX && fused_panels_enabled())
-        return rsvd_split_fused(a, h, stream, theta, rows, cols, k_keep, l, q, omega, abs_err, rel_err, m1, m2, capacity,
+        return rsvd_split_fused(a, h, device, stream, theta, rows, cols, k_keep, l, q, omega, abs_err, rel_err, m1, m2, capacity,
                                 rank_out, s_host);
     DeviceBuffers buf;
+    buf.reserve(device, sizeof(amp_t) * ((n + m) * L + L + L * m + L * kk + kk * m + n * static_cast<uint64_t>(k_keep) +
+                                         (wide ? 0 : n * m)) + 16 * kk + 8192);
     amp_t *A = nullptr, *Qn = nullptr, *Qm = nullptr, *tau = nullptr, *B = nullptr, *UB = nullptr, *VB = nullptr;
     double *dS = nullptr, *dE = nullptr;
     rocblas_int *dinfo = nullptr;
