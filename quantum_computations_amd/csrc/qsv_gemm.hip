@@ -219,7 +219,7 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_scale_strided(const amp_t *__rest
 // l = k + 10 <= 64 columns are hundreds of microsecond-sized launches each (profiles/r01_mps_kernel_stats.csv: half of
 // the GPU time of a split), and the range finder re-orthonormalises 15 times.  Any orthonormal basis of the same
 // subspace gives the same U S Vh, so the panels are orthonormalised by shifted CholeskyQR3 (Fukaya et al., SIAM J.
-// Sci. Comput. 42, 2020): three rounds of  G = Y^H Y,  R = chol(G + shift I),  Y <- Y R^-1  -- three launches per
+// Sci. Comput. 42, 2020): three rounds of  G = Y^H Y,  R = chol(G + shift I),  Y <- Y R^-1 (a triangular solve per row)  -- three launches per
 // round, every one a single pass over the panel; the shift of the first round makes the factorisation succeed for
 // condition numbers up to 1/u, directions that are numerically absent are detected by their pivot in the later
 // rounds and dropped (zero columns; Householder QR would invent arbitrary complements there).  The (l x m) projection
@@ -283,21 +283,21 @@ __global__ __launch_bounds__(256) void k_panel_gram(const amp_t *__restrict__ Y,
 __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ partials, int nblocks, int l,
                                                      uint64_t rows, int first_round,
                                                      const amp_t *__restrict__ r_prev, amp_t *__restrict__ r_total,
-                                                     amp_t *__restrict__ r_inv) {
+                                                     amp_t *__restrict__ r_out) {
     __shared__ amp_t G[LMAX * LMAX];
-    __shared__ amp_t Inv[LMAX * LMAX];
+    __shared__ amp_t Stage[LMAX * LMAX];
     __shared__ double pivot_floor, shift;
     __shared__ int absent[LMAX];
     const int t = threadIdx.x, entries = l * l;
     for (int e = t; e < entries; e += 256) {
         amp_t s = {0.0, 0.0};
         int b = 0;
-        for (; b + 8 <= nblocks; b += 8) {          // eight independent loads in flight, summed in block order
-            amp_t v[8];
+        for (; b + 32 <= nblocks; b += 32) {        // 32 independent loads in flight, summed in block order
+            amp_t v[32];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = partials[static_cast<size_t>(b + k) * entries + e];
+            for (int k = 0; k < 32; ++k) v[k] = partials[static_cast<size_t>(b + k) * entries + e];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 32; ++k) {
                 s.x += v[k].x;
                 s.y += v[k].y;
             }
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
             absent[j] = gone;
         }
         for (int k = j + 1 + t; k < l; k += 256) {
-            amp_t v = G[j * l + k];
+            const amp_t v = G[j * l + k];
             G[j * l + k] = gone ? amp_t{0.0, 0.0} : amp_t{v.x / rjj, v.y / rjj};
         }
         __syncthreads();
@@ -348,28 +348,11 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
         }
     }
     __syncthreads();
-    // R^-1 by back substitution, one column per thread
-    for (int c = t; c < l; c += 256) {
-        for (int i = 0; i < l; ++i) Inv[i * l + c] = amp_t{0.0, 0.0};
-        if (!absent[c]) {
-            Inv[c * l + c] = amp_t{1.0 / G[c * l + c].x, 0.0};
-            for (int i = c - 1; i >= 0; --i) {
-                amp_t sum = {0.0, 0.0};
-                for (int k = i + 1; k <= c; ++k) {
-                    const amp_t p = plain_mul(G[i * l + k], Inv[k * l + c]);
-                    sum.x += p.x;
-                    sum.y += p.y;
-                }
-                const double d = G[i * l + i].x;
-                Inv[i * l + c] = amp_t{-sum.x / d, -sum.y / d};
-            }
-        }
-    }
-    __syncthreads();
     for (int e = t; e < entries; e += 256) {
-        r_inv[e] = Inv[e];
+        const int i = e / l, k = e % l;
+        // the factor handed to k_panel_solve: upper triangle, diagonal 0 marks an absent direction
+        r_out[e] = (k < i || absent[i]) ? amp_t{0.0, 0.0} : G[e];
         if (r_total) {
-            const int i = e / l, k = e % l;
             amp_t sum = {0.0, 0.0};
             if (absent[i]) {
                 // the panel column of an absent direction is zero: its row of the factor must not reach the SVD
@@ -382,36 +365,51 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
             } else if (k >= i) {
                 sum = G[e];
             }
-            Inv[e] = sum;   // staged: r_total may alias r_prev
+            Stage[e] = sum;   // staged: r_total may alias r_prev
         }
     }
     __syncthreads();
     if (r_total)
-        for (int e = t; e < entries; e += 256) r_total[e] = Inv[e];
+        for (int e = t; e < entries; e += 256) r_total[e] = Stage[e];
 }
 
-// Y <- Y * r_inv (upper triangular, row-major [i * l + j]) in place, one 64-row tile per pass
-__global__ __launch_bounds__(256) void k_panel_apply(amp_t *__restrict__ Y, uint64_t n, int l,
-                                                    const amp_t *__restrict__ r_inv) {
+// Y <- Y R^-1 in place for the upper triangular R of k_panel_factor (row-major [i * l + j]), as a forward substitution per
+// row: q_j = (y_j - sum_{i<j} q_i R[i][j]) / R[j][j], q_j = 0 for absent directions (R[j][j] == 0).  One thread per row,
+// 64 rows per workgroup staged through LDS (coalesced both ways); R is wave-uniform, i.e. scalar loads.
+__global__ __launch_bounds__(PANEL_ROWS) void k_panel_solve(amp_t *__restrict__ Y, uint64_t n, int l,
+                                                           const amp_t *__restrict__ R) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     amp_t *tile = reinterpret_cast<amp_t *>(smem_raw);   // [l][PANEL_PITCH]
-    const int t = threadIdx.x, r = t % PANEL_ROWS, lane_group = t / PANEL_ROWS;
+    amp_t *Rs = tile + l * PANEL_PITCH;                  // [l][l], column-major copy: Rs[j * l + i] = R[i][j]
+    const int r = threadIdx.x;
+    for (int e = r; e < l * l; e += PANEL_ROWS) Rs[(e % l) * l + e / l] = R[e];
     for (uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * PANEL_ROWS; r0 < n;
          r0 += static_cast<uint64_t>(gridDim.x) * PANEL_ROWS) {
+        const bool inside = r0 + r < n;
         __syncthreads();
-        for (int idx = t; idx < l * PANEL_ROWS; idx += 256) {
-            const int c = idx / PANEL_ROWS, rr = idx % PANEL_ROWS;
-            tile[c * PANEL_PITCH + rr] = r0 + rr < n ? Y[static_cast<uint64_t>(c) * n + r0 + rr] : amp_t{0.0, 0.0};
-        }
-        __syncthreads();
-        for (int j = lane_group; j < l; j += 256 / PANEL_ROWS) {   // j is wave-uniform: r_inv comes through scalar loads
-            amp_t acc = {0.0, 0.0};
-            for (int i = 0; i <= j; ++i) {
-                const amp_t p = plain_mul(tile[i * PANEL_PITCH + r], r_inv[i * l + j]);
-                acc.x += p.x;
-                acc.y += p.y;
+        for (int c = 0; c < l; ++c)
+            tile[c * PANEL_PITCH + r] = inside ? Y[static_cast<uint64_t>(c) * n + r0 + r] : amp_t{0.0, 0.0};
+        for (int j = 0; j < l; ++j) {
+            const amp_t *col = Rs + j * l;               // R[0..j][j], read by every lane at once (LDS broadcast)
+            amp_t acc = tile[j * PANEL_PITCH + r];
+            int i = 0;
+            for (; i + 4 <= j; i += 4) {                 // four independent products per step hide the LDS latency
+                const amp_t p0 = plain_mul(tile[(i + 0) * PANEL_PITCH + r], col[i + 0]);
+                const amp_t p1 = plain_mul(tile[(i + 1) * PANEL_PITCH + r], col[i + 1]);
+                const amp_t p2 = plain_mul(tile[(i + 2) * PANEL_PITCH + r], col[i + 2]);
+                const amp_t p3 = plain_mul(tile[(i + 3) * PANEL_PITCH + r], col[i + 3]);
+                acc.x -= (p0.x + p1.x) + (p2.x + p3.x);
+                acc.y -= (p0.y + p1.y) + (p2.y + p3.y);
             }
-            if (r0 + r < n) Y[static_cast<uint64_t>(j) * n + r0 + r] = acc;
+            for (; i < j; ++i) {
+                const amp_t p = plain_mul(tile[i * PANEL_PITCH + r], col[i]);
+                acc.x -= p.x;
+                acc.y -= p.y;
+            }
+            const double d = col[j].x;
+            const amp_t q = d != 0.0 ? amp_t{acc.x / d, acc.y / d} : amp_t{0.0, 0.0};
+            tile[j * PANEL_PITCH + r] = q;       // only this thread reads or writes row r of the tile
+            if (inside) Y[static_cast<uint64_t>(j) * n + r0 + r] = q;
         }
     }
 }
@@ -636,16 +634,20 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
 
 // Shifted CholeskyQR3 of the column-major (n x l) panel Y, in place.  `r_total` (l x l, row-major, may be null) receives
 // the triangular factor with  Y_in = Y_out * r_total.
-int panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t *partials, amp_t *r_inv,
+int panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t *partials, amp_t *r_factor,
                          amp_t *r_total) {
     const size_t lds = sizeof(amp_t) * l * PANEL_PITCH;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_panel_gram),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LMAX * PANEL_PITCH * sizeof(amp_t))));
-        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_panel_apply),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LMAX * PANEL_PITCH * sizeof(amp_t))));
         raised = true;
+    }
+    static bool raised_solve = false;
+    if (lds + sizeof(amp_t) * l * l > 64 * 1024 && !raised_solve) {
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_panel_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>((LMAX * PANEL_PITCH + LMAX * LMAX) * sizeof(amp_t))));
+        raised_solve = true;
     }
     const uint64_t tiles = (n + PANEL_ROWS - 1) / PANEL_ROWS;
     const int gram_blocks = static_cast<int>(tiles < GRAM_BLOCKS ? tiles : GRAM_BLOCKS);
@@ -653,8 +655,9 @@ int panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t 
     for (int round = 0; round < 3; ++round) {
         hipLaunchKernelGGL(k_panel_gram, dim3(gram_blocks), dim3(256), lds, stream, Y, n, l, partials);
         hipLaunchKernelGGL(k_panel_factor, dim3(1), dim3(256), 0, stream, partials, gram_blocks, l, n, round == 0,
-                           round == 0 ? nullptr : r_total, r_total, r_inv);
-        hipLaunchKernelGGL(k_panel_apply, dim3(apply_blocks), dim3(256), lds, stream, Y, n, l, r_inv);
+                           round == 0 ? nullptr : r_total, r_total, r_factor);
+        hipLaunchKernelGGL(k_panel_solve, dim3(apply_blocks), dim3(PANEL_ROWS), lds + sizeof(amp_t) * l * l, stream, Y, n, l,
+                           r_factor);
     }
     QSV_HIP(hipGetLastError());
     return QSV_OK;
@@ -681,12 +684,12 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
                                          (wide ? 0 : n * m)) + 8 * L + 8192);
     amp_t *A = nullptr, *Qn = nullptr, *Qm = nullptr, *partials = nullptr, *small = nullptr, *UA = nullptr, *VA = nullptr;
     double *dS = nullptr;
-    // small: r_inv | r_total | U_r | V_r, each L x L
+    // small: r_factor | r_total | U_r | V_r, each L x L
     if (!buf.alloc(&Qn, sizeof(amp_t) * n * L) || !buf.alloc(&Qm, sizeof(amp_t) * m * L) ||
         !buf.alloc(&partials, sizeof(amp_t) * GRAM_BLOCKS * L * L) || !buf.alloc(&small, sizeof(amp_t) * 4 * L * L) ||
         !buf.alloc(&dS, sizeof(double) * L))
         return qsv_fail(QSV_ENOMEM, "device allocation of the randomized-SVD workspace failed");
-    amp_t *r_inv = small, *r_total = small + L * L, *Ur = small + 2 * L * L, *Vr = small + 3 * L * L;
+    amp_t *r_factor = small, *r_total = small + L * L, *Ur = small + 2 * L * L, *Vr = small + 3 * L * L;
     if (wide) {
         A = const_cast<amp_t *>(theta);      // row-major (rows x cols) read column-major is theta^T = A
     } else {
@@ -708,16 +711,16 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
     };
     const rocblas_operation N = rocblas_operation_none, Cc = rocblas_operation_conjugate_transpose;
     bool ok = gemm(N, N, ni, li, mi, A, ni, omega, mi, Qn, ni);                                   // Y = A O
-    int rc = ok ? panel_orthonormalise(stream, Qn, n, l, partials, r_inv, nullptr) : QSV_OK;
+    int rc = ok ? panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr) : QSV_OK;
     for (int it = 0; ok && !rc && it < q; ++it) {
         ok = gemm(Cc, N, mi, li, ni, A, ni, Qn, ni, Qm, mi);                                      // Y = A^H Q
-        if (ok) rc = panel_orthonormalise(stream, Qm, m, l, partials, r_inv, nullptr);
+        if (ok) rc = panel_orthonormalise(stream, Qm, m, l, partials, r_factor, nullptr);
         ok = ok && !rc && gemm(N, N, ni, li, mi, A, ni, Qm, mi, Qn, ni);                          // Y = A Q
-        if (ok) rc = panel_orthonormalise(stream, Qn, n, l, partials, r_inv, nullptr);
+        if (ok) rc = panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr);
     }
     // B^H = A^H Q = Qb Rb  (m x l);  Rb = Ur S Vr^H;  A ~ (Q Vr) S (Qb Ur)^H
     ok = ok && !rc && gemm(Cc, N, mi, li, ni, A, ni, Qn, ni, Qm, mi);
-    if (ok) rc = panel_orthonormalise(stream, Qm, m, l, partials, r_inv, r_total);
+    if (ok) rc = panel_orthonormalise(stream, Qm, m, l, partials, r_factor, r_total);
     if (!ok) return qsv_fail(QSV_EHIP, "rocBLAS call failed in the randomized range finder");
     if (rc) return rc;
     hipLaunchKernelGGL(k_small_svd, dim3(1), dim3(256), 0, stream, r_total, l, Ur, dS, Vr);
