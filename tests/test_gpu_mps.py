@@ -98,3 +98,26 @@ def test_randomized_split_on_a_low_rank_matrix():
         m1, m2 = tensor_svd(t, [0, 1], [2, 3], max_bond_dim=8, rng_seed=11)
         assert m1.shape[-1] == 6        # the tail of the 8 kept values is below rel_err * sum
         assert maxdiff(np.tensordot(m1, m2, axes=1).reshape(matrix.shape), matrix) < 1e-9 * np.abs(matrix).max()
+
+
+def test_library_qr_path_of_the_randomized_split_still_works():
+    """``QSV_RSVD=rocsolver`` selects rocSOLVER's Householder QR / gesvd instead of the fused panel kernels; the choice is
+    read once per process, so the check runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from quantum_computations_amd.cv_simulator.mps import tensor_svd\n"
+        "rng = np.random.default_rng(4)\n"
+        "a = (rng.standard_normal((150, 5)) + 1j * rng.standard_normal((150, 5))) @ "
+        "(rng.standard_normal((5, 170)) + 1j * rng.standard_normal((5, 170)))\n"
+        "m1, m2 = tensor_svd(a.reshape(150, 1, 1, 170), [0, 1], [2, 3], max_bond_dim=7, rng_seed=3)\n"
+        "assert m1.shape[-1] == 5, m1.shape\n"
+        "err = np.max(np.abs(np.tensordot(m1, m2, axes=1).reshape(a.shape) - a))\n"
+        "assert err < 1e-9 * np.abs(a).max(), err\n"
+        "print('ok')\n")
+    env = dict(os.environ, QSV_RSVD="rocsolver")
+    repo = str(Path(__file__).resolve().parent.parent)
+    done = subprocess.run([sys.executable, "-c", code], cwd=repo, env=env, capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0 and "ok" in done.stdout, done.stderr[-2000:]
