@@ -229,8 +229,9 @@ class SiteRegister:
             self.split_counts["exact"] += 1
         r = int(rank.value)
         self.last_singular_values = s
-        # the library wrote compact (rows x r) and (r x cols) matrices at the start of the buffers
-        return m1.view(-1)[: rows * r].view(rows, r), m2.view(-1)[: r * cols].view(r, cols), r
+        # the library wrote compact (rows x r) and (r x cols) matrices at the start of the buffers; copy them out so that
+        # the sites do not pin buffers sized for the untruncated rank (theta-sized when there is no cap)
+        return (m1.view(-1)[: rows * r].view(rows, r).clone(), m2.view(-1)[: r * cols].view(r, cols).clone(), r)
 
     def _store_pair(self, left: int, m1, m2, cl: int, cr: int, r: int) -> None:
         self.sites[left] = m1.reshape(cl, self.d, r)
