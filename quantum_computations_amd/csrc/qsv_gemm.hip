@@ -632,6 +632,243 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
     return QSV_OK;
 }
 
+// ----------------------------------------------------------------------------------------------------
+// Tall-skinny products of the range finder on the f64 matrix cores.
+//
+//   k_skinny_nn :  Y (n x l) = A (n x m) . Q (m x l)          k_skinny_cn :  Y (m x l) = A^H (m x n) . Q (n x l)
+//
+// A is the big operand (column-major, ld n: gigabytes), Q / Y are panels of l <= 64 columns.  rocBLAS pads such panels
+// to a 64-wide macro tile and streams A at 2.2 TB/s whatever l is; these kernels tile l in steps of 16
+// (v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], D col = lane & 15,
+// row = (lane >> 4) + 4 reg), stage the Q slab through LDS once per workgroup and keep A as one 16-byte load per lane
+// per k-step.  A complex product is four real MFMAs; one wave owns 16 rows (nn) or 16 columns (cn) of A.
+// The sum over k may be taken in any order as long as both operands use the same one: the cn kernel lets a lane
+// fetch two consecutive rows (32 contiguous bytes) and spends them on two successive MFMA steps, so that the four lane
+// groups cover whole 128-byte lines of every column.
+// ----------------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int SK_SLAB = 32;           // k values per LDS slab of Q
+
+template <int T>                      // T = number of 16-column tiles of the panel (l <= 16 T)
+__global__ __launch_bounds__(256) void k_skinny_nn(const amp_t *__restrict__ A, const amp_t *__restrict__ Q,
+                                                  amp_t *__restrict__ Y, uint64_t n, uint64_t m, int l) {
+    __shared__ amp_t slab[2][SK_SLAB][16 * T];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const uint64_t row = static_cast<uint64_t>(blockIdx.x) * 64 + wave * 16 + li;
+    const bool row_ok = row < n;
+    f64x4 cre[T], cim[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) cre[j] = cim[j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const uint64_t all_slabs = (m + SK_SLAB - 1) / SK_SLAB;
+    // split-K: blockIdx.y takes a contiguous share of the slabs; with two shares the two partial sums meet in a
+    // zero-initialised Y through atomic adds, and a + b does not depend on which arrives first
+    const uint64_t s_begin = all_slabs * blockIdx.y / gridDim.y, slabs = all_slabs * (blockIdx.y + 1) / gridDim.y;
+    constexpr int QREGS = SK_SLAB * 16 * T / 256;     // slab entries per thread
+    amp_t q_next[QREGS];
+    auto load_q = [&](uint64_t s) {              // Q[k0 + k][j] of slab s -> registers, zero padded
+        const uint64_t k0 = s * SK_SLAB;
+#pragma unroll
+        for (int u = 0; u < QREGS; ++u) {
+            const int e = t + 256 * u, k = e % SK_SLAB, j = e / SK_SLAB;
+            q_next[u] = (k0 + k < m && j < l) ? Q[static_cast<uint64_t>(j) * m + k0 + k] : amp_t{0.0, 0.0};
+        }
+    };
+    auto store_q = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < QREGS; ++u) {
+            const int e = t + 256 * u;
+            slab[buf][e % SK_SLAB][e / SK_SLAB] = q_next[u];
+        }
+    };
+    amp_t a_now[SK_SLAB / 4], a_next[SK_SLAB / 4];
+    auto fetch = [&](amp_t *dst, uint64_t s) {
+        const uint64_t k0 = s * SK_SLAB;
+#pragma unroll
+        for (int q = 0; q < SK_SLAB / 4; ++q) {
+            const uint64_t k = k0 + 4 * q + lk;
+            dst[q] = (row_ok && k < m) ? __builtin_nontemporal_load(A + k * n + row) : amp_t{0.0, 0.0};
+        }
+    };
+    load_q(s_begin);
+    store_q(s_begin & 1);
+    fetch(a_now, s_begin);
+    for (uint64_t s = s_begin; s < slabs; ++s) {
+        const int buf = s & 1;
+        __syncthreads();                               // slab[buf] is complete, slab[buf ^ 1] is free
+        const bool more = s + 1 < slabs;
+        if (more) {                                    // loads for the next slab fly while this one is multiplied
+            load_q(s + 1);
+            fetch(a_next, s + 1);
+        }
+#pragma unroll
+        for (int q = 0; q < SK_SLAB / 4; ++q) {
+            const double are = a_now[q].x, aim = a_now[q].y;
+            amp_t b[T];
+#pragma unroll
+            for (int j = 0; j < T; ++j) b[j] = slab[buf][4 * q + lk][16 * j + li];
+#pragma unroll
+            for (int j = 0; j < T; ++j) {        // dependent updates of one accumulator stay 2 T instructions apart
+                cre[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(are, b[j].x, cre[j], 0, 0, 0);
+                cim[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(are, b[j].y, cim[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                cre[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aim, b[j].y, cre[j], 0, 0, 0);
+                cim[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim, b[j].x, cim[j], 0, 0, 0);
+            }
+        }
+        if (more) {
+            store_q(buf ^ 1);
+#pragma unroll
+            for (int q = 0; q < SK_SLAB / 4; ++q) a_now[q] = a_next[q];
+        }
+    }
+    // D: col = lane & 15, row = (lane >> 4) + 4 reg
+    const uint64_t row_base = static_cast<uint64_t>(blockIdx.x) * 64 + wave * 16;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const int col = 16 * j + li;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const uint64_t r = row_base + lk + 4 * reg;
+            if (r < n && col < l) {
+                amp_t *dst = Y + static_cast<uint64_t>(col) * n + r;
+                if (gridDim.y == 1) {
+                    *dst = amp_t{cre[j][reg], cim[j][reg]};
+                } else {
+                    atomicAdd(reinterpret_cast<double *>(dst), cre[j][reg]);
+                    atomicAdd(reinterpret_cast<double *>(dst) + 1, cim[j][reg]);
+                }
+            }
+        }
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void k_skinny_cn(const amp_t *__restrict__ A, const amp_t *__restrict__ Q,
+                                                  amp_t *__restrict__ Y, uint64_t n, uint64_t m, int l) {
+    __shared__ amp_t slab[2][SK_SLAB][16 * T];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const uint64_t col = static_cast<uint64_t>(blockIdx.x) * 64 + wave * 16 + li;   // column of A = output row
+    const bool col_ok = col < m;
+    f64x4 cre[T], cim[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) cre[j] = cim[j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const uint64_t all_slabs = (n + SK_SLAB - 1) / SK_SLAB;
+    const uint64_t s_begin = all_slabs * blockIdx.y / gridDim.y, slabs = all_slabs * (blockIdx.y + 1) / gridDim.y;
+    constexpr int QREGS = SK_SLAB * 16 * T / 256;
+    amp_t q_next[QREGS];
+    auto load_q = [&](uint64_t s) {              // Q[r0 + k][j] of slab s -> registers
+        const uint64_t r0 = s * SK_SLAB;
+#pragma unroll
+        for (int u = 0; u < QREGS; ++u) {
+            const int e = t + 256 * u, k = e % SK_SLAB, j = e / SK_SLAB;
+            q_next[u] = (r0 + k < n && j < l) ? Q[static_cast<uint64_t>(j) * n + r0 + k] : amp_t{0.0, 0.0};
+        }
+    };
+    auto store_q = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < QREGS; ++u) {
+            const int e = t + 256 * u;
+            slab[buf][e % SK_SLAB][e / SK_SLAB] = q_next[u];
+        }
+    };
+    // rows of a slab in blocks of 8: lane group lk owns rows 8 b + 2 lk and 8 b + 2 lk + 1 (32 contiguous bytes)
+    amp_t a_now[SK_SLAB / 4], a_next[SK_SLAB / 4];
+    auto fetch = [&](amp_t *dst, uint64_t s) {
+        const uint64_t r0 = s * SK_SLAB;
+#pragma unroll
+        for (int b = 0; b < SK_SLAB / 8; ++b)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint64_t r = r0 + 8 * b + 2 * lk + h;
+                dst[2 * b + h] = (col_ok && r < n) ? __builtin_nontemporal_load(A + col * n + r) : amp_t{0.0, 0.0};
+            }
+    };
+    load_q(s_begin);
+    store_q(s_begin & 1);
+    fetch(a_now, s_begin);
+    for (uint64_t s = s_begin; s < slabs; ++s) {
+        const int buf = s & 1;
+        __syncthreads();
+        const bool more = s + 1 < slabs;
+        if (more) {
+            load_q(s + 1);
+            fetch(a_next, s + 1);
+        }
+#pragma unroll
+        for (int b = 0; b < SK_SLAB / 8; ++b)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double are = a_now[2 * b + h].x, aim = a_now[2 * b + h].y;     // conj(A): (are, -aim)
+                amp_t q[T];
+#pragma unroll
+                for (int j = 0; j < T; ++j) q[j] = slab[buf][8 * b + 2 * lk + h][16 * j + li];
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    cre[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(are, q[j].x, cre[j], 0, 0, 0);
+                    cim[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(are, q[j].y, cim[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    cre[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim, q[j].y, cre[j], 0, 0, 0);
+                    cim[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aim, q[j].x, cim[j], 0, 0, 0);
+                }
+            }
+        if (more) {
+            store_q(buf ^ 1);
+#pragma unroll
+            for (int q = 0; q < SK_SLAB / 4; ++q) a_now[q] = a_next[q];
+        }
+    }
+    const uint64_t out_base = static_cast<uint64_t>(blockIdx.x) * 64 + wave * 16;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const int pc = 16 * j + li;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const uint64_t r = out_base + lk + 4 * reg;
+            if (r < m && pc < l) {
+                amp_t *dst = Y + static_cast<uint64_t>(pc) * m + r;
+                if (gridDim.y == 1) {
+                    *dst = amp_t{cre[j][reg], cim[j][reg]};
+                } else {
+                    atomicAdd(reinterpret_cast<double *>(dst), cre[j][reg]);
+                    atomicAdd(reinterpret_cast<double *>(dst) + 1, cim[j][reg]);
+                }
+            }
+        }
+    }
+}
+
+// Y = A Q (conj_transpose == 0: A is n x m, Q is m x l, Y is n x l) or Y = A^H Q (A is n x m, Q is n x l, Y is m x l);
+// everything column-major with tight leading dimensions.  Returns false when the shape is outside what the kernels take
+// (l > 64) so that the caller can use the library instead.
+bool skinny_gemm(hipStream_t stream, bool conj_transpose, const amp_t *A, const amp_t *Q, amp_t *Y, uint64_t n,
+                 uint64_t m, int l) {
+    if (l < 1 || l > 64) return false;
+    const int tiles = (l + 15) / 16;
+    const uint64_t out_rows = conj_transpose ? m : n;
+    const unsigned row_blocks = static_cast<unsigned>((out_rows + 63) / 64);
+    // one wave per SIMD cannot hide its own load latency: below two workgroups per CU the k range is cut in two
+    const unsigned split = row_blocks < 512 && (conj_transpose ? n : m) >= 4 * SK_SLAB ? 2 : 1;
+    if (split > 1 && hipMemsetAsync(Y, 0, sizeof(amp_t) * out_rows * l, stream) != hipSuccess) return false;
+    const dim3 grid(row_blocks, split), block(256);
+#define QSV_SKINNY(T)                                                                                         \
+    if (conj_transpose) hipLaunchKernelGGL(k_skinny_cn<T>, grid, block, 0, stream, A, Q, Y, n, m, l);         \
+    else hipLaunchKernelGGL(k_skinny_nn<T>, grid, block, 0, stream, A, Q, Y, n, m, l)
+    switch (tiles) {
+        case 1: QSV_SKINNY(1); break;
+        case 2: QSV_SKINNY(2); break;
+        case 3: QSV_SKINNY(3); break;
+        default: QSV_SKINNY(4); break;
+    }
+#undef QSV_SKINNY
+    return hipGetLastError() == hipSuccess;
+}
+
 // Shifted CholeskyQR3 of the column-major (n x l) panel Y, in place.  `r_total` (l x l, row-major, may be null) receives
 // the triangular factor with  Y_in = Y_out * r_total.
 int panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t *partials, amp_t *r_factor,
@@ -710,16 +947,23 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
                rocblas_status_success;
     };
     const rocblas_operation N = rocblas_operation_none, Cc = rocblas_operation_conjugate_transpose;
-    bool ok = gemm(N, N, ni, li, mi, A, ni, omega, mi, Qn, ni);                                   // Y = A O
+    // the passes over A: the MFMA panel kernels (l tiled by 16), rocBLAS if they decline the shape
+    auto times_a = [&](const amp_t *panel, amp_t *out) {          // out (n x l) = A panel (m x l)
+        return skinny_gemm(stream, false, A, panel, out, n, m, l) || gemm(N, N, ni, li, mi, A, ni, panel, mi, out, ni);
+    };
+    auto times_ah = [&](const amp_t *panel, amp_t *out) {         // out (m x l) = A^H panel (n x l)
+        return skinny_gemm(stream, true, A, panel, out, n, m, l) || gemm(Cc, N, mi, li, ni, A, ni, panel, ni, out, mi);
+    };
+    bool ok = times_a(omega, Qn);                                                                 // Y = A O
     int rc = ok ? panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr) : QSV_OK;
     for (int it = 0; ok && !rc && it < q; ++it) {
-        ok = gemm(Cc, N, mi, li, ni, A, ni, Qn, ni, Qm, mi);                                      // Y = A^H Q
+        ok = times_ah(Qn, Qm);                                                                    // Y = A^H Q
         if (ok) rc = panel_orthonormalise(stream, Qm, m, l, partials, r_factor, nullptr);
-        ok = ok && !rc && gemm(N, N, ni, li, mi, A, ni, Qm, mi, Qn, ni);                          // Y = A Q
+        ok = ok && !rc && times_a(Qm, Qn);                                                        // Y = A Q
         if (ok) rc = panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr);
     }
     // B^H = A^H Q = Qb Rb  (m x l);  Rb = Ur S Vr^H;  A ~ (Q Vr) S (Qb Ur)^H
-    ok = ok && !rc && gemm(Cc, N, mi, li, ni, A, ni, Qn, ni, Qm, mi);
+    ok = ok && !rc && times_ah(Qn, Qm);
     if (ok) rc = panel_orthonormalise(stream, Qm, m, l, partials, r_factor, r_total);
     if (!ok) return qsv_fail(QSV_EHIP, "rocBLAS call failed in the randomized range finder");
     if (rc) return rc;
@@ -900,4 +1144,13 @@ int qsvg_axis_gemm(int device, hipStream_t stream, const amp_t *in, amp_t *out, 
     }
     if (s != rocblas_status_success) return qsv_fail(QSV_EHIP, "rocblas_zgemm_strided_batched failed");
     return 1;
+}
+
+// Column-major tall-skinny product on the f64 matrix cores (see k_skinny_nn / k_skinny_cn).
+int qsvg_skinny_gemm(int device, hipStream_t stream, int conj_transpose, uint64_t n, uint64_t m, int l, const amp_t *A,
+                     const amp_t *Q, amp_t *Y) {
+    QSV_HIP(hipSetDevice(device));
+    if (!skinny_gemm(stream, conj_transpose != 0, A, Q, Y, n, m, l))
+        return qsv_fail(QSV_EINVAL, "panel width must be 1..64 columns");
+    return QSV_OK;
 }
