@@ -121,3 +121,31 @@ def test_library_qr_path_of_the_randomized_split_still_works():
     repo = str(Path(__file__).resolve().parent.parent)
     done = subprocess.run([sys.executable, "-c", code], cwd=repo, env=env, capture_output=True, text=True, timeout=300)
     assert done.returncode == 0 and "ok" in done.stdout, done.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n,m,l", [(100, 70, 5), (257, 129, 16), (1000, 333, 26), (2049, 515, 42), (130, 1027, 64),
+                                   (64, 32, 1), (4096, 4096, 33)])
+def test_mfma_tall_skinny_products(n, m, l):
+    """``qsv_tensor_skinny_gemm``: Y = A Q and Y = A^H Q (column-major) on the f64 matrix cores, ragged shapes, with and
+    without the split of the k range."""
+    import ctypes as C
+
+    import torch
+
+    from quantum_computations_amd import _lib
+    rng = np.random.default_rng(n + m + l)
+    a = rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m))
+    dev_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()             # row-major A^T == column-major A
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for conj, rows_q, rows_y in ((0, m, n), (1, n, m)):
+        q = rng.standard_normal((rows_q, l)) + 1j * rng.standard_normal((rows_q, l))
+        dev_q = torch.from_numpy(np.ascontiguousarray(q.T)).cuda()
+        dev_y = torch.empty(l, rows_y, dtype=torch.complex128, device="cuda")
+        _lib.call("qsv_tensor_skinny_gemm", 0, stream, conj, n, m, l, C.c_void_p(dev_a.data_ptr()),
+                  C.c_void_p(dev_q.data_ptr()), C.c_void_p(dev_y.data_ptr()))
+        torch.cuda.synchronize()
+        want = (a.conj().T if conj else a) @ q
+        assert maxdiff(dev_y.cpu().numpy().T, want) < 1e-12 * np.abs(want).max()
+    with pytest.raises(ValueError):
+        _lib.call("qsv_tensor_skinny_gemm", 0, stream, 0, n, m, 65, C.c_void_p(dev_a.data_ptr()),
+                  C.c_void_p(dev_a.data_ptr()), C.c_void_p(dev_a.data_ptr()))
