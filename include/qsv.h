@@ -206,12 +206,13 @@ int qsv_tensor_rsvd_split(int device, void *hip_stream, const void *dev_theta, u
                           int64_t max_bond_dim, int probes, int power_iterations, const void *dev_omega,
                           double abs_err, double rel_err, void *dev_m1, void *dev_m2, uint64_t capacity,
                           uint64_t *rank, double *singular_values /* max_bond_dim doubles or NULL */);
-/* Tall-skinny product on the f64 matrix cores, COLUMN-major with tight leading dimensions: with A (n x m),
- * conj_transpose == 0: Y (n x l) = A . Q (m x l);  conj_transpose != 0: Y (m x l) = A^H . Q (n x l);  1 <= l <= 64.
- * The building block of the range finder (A @ O, A^H @ Q, A @ Q of mps.py:15-21), where A is gigabytes and the panel a
- * few dozen columns: l is tiled in steps of 16 instead of the library's 64-wide macro tile. */
-int qsv_tensor_skinny_gemm(int device, void *hip_stream, int conj_transpose, uint64_t n, uint64_t m, int l,
-                           const void *dev_a, const void *dev_q, void *dev_y);
+/* Tall-skinny product on the f64 matrix cores, COLUMN-major with tight leading dimensions: Y = op(A) . Q with A (n x m)
+ * and a panel of 1 <= l <= 64 columns; op: 0 = A, 3 = conj(A) (Q is m x l, Y is n x l); 1 = A^H, 2 = A^T (Q is n x l,
+ * Y is m x l).  The building block of the range finder (A @ O, A^H @ Q, A @ Q of mps.py:15-21), where A is gigabytes
+ * and the panel a few dozen columns: l is tiled in steps of 16 instead of the library's 64-wide macro tile, and the
+ * transposed / conjugated forms let a row-major theta be used in either orientation without a re-ordered copy. */
+int qsv_tensor_skinny_gemm(int device, void *hip_stream, int op, uint64_t n, uint64_t m, int l, const void *dev_a,
+                           const void *dev_q, void *dev_y);
 /* t[l, j, r] *= diag[j] in place: Z and P on a site (gates.py:223,245). */
 int qsv_tensor_scale_axis(int device, void *hip_stream, void *dev_t, uint64_t L, uint64_t d, uint64_t R,
                           const void *dev_diag /* d */);

@@ -789,11 +789,12 @@ int qsv_tensor_rsvd_split(int device, void *hip_stream, const void *dev_theta, u
                            rank, singular_values);
 }
 
-int qsv_tensor_skinny_gemm(int device, void *hip_stream, int conj_transpose, uint64_t n, uint64_t m, int l,
-                           const void *dev_a, const void *dev_q, void *dev_y) {
+int qsv_tensor_skinny_gemm(int device, void *hip_stream, int op, uint64_t n, uint64_t m, int l, const void *dev_a,
+                           const void *dev_q, void *dev_y) {
     if (!dev_a || !dev_q || !dev_y) return qsv_fail(QSV_EINVAL, "null pointer");
     if (n == 0 || m == 0) return qsv_fail(QSV_EINVAL, "empty matrix");
-    return qsvg_skinny_gemm(device, as_stream(hip_stream), conj_transpose, n, m, l, camp(dev_a), camp(dev_q), amp(dev_y));
+    if (op < 0 || op > 3) return qsv_fail(QSV_EINVAL, "op must be 0 (A), 1 (A^H), 2 (A^T) or 3 (conj A)");
+    return qsvg_skinny_gemm(device, as_stream(hip_stream), op, n, m, l, camp(dev_a), camp(dev_q), amp(dev_y));
 }
 
 int qsv_tensor_scale_axis(int device, void *hip_stream, void *dev_t, uint64_t L, uint64_t d, uint64_t R,

@@ -651,7 +651,8 @@ constexpr int SK_SLAB = 32;           // k values per LDS slab of Q
 
 template <int T>                      // T = number of 16-column tiles of the panel (l <= 16 T)
 __global__ __launch_bounds__(256) void k_skinny_nn(const amp_t *__restrict__ A, const amp_t *__restrict__ Q,
-                                                  amp_t *__restrict__ Y, uint64_t n, uint64_t m, int l) {
+                                                  amp_t *__restrict__ Y, uint64_t n, uint64_t m, int l,
+                                                  double im_sign) {
     __shared__ amp_t slab[2][SK_SLAB][16 * T];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(256) void k_skinny_nn(const amp_t *__restrict__ A, 
         }
 #pragma unroll
         for (int q = 0; q < SK_SLAB / 4; ++q) {
-            const double are = a_now[q].x, aim = a_now[q].y;
+            const double are = a_now[q].x, aim = im_sign * a_now[q].y;   // im_sign = -1: conj(A) Q
             amp_t b[T];
 #pragma unroll
             for (int j = 0; j < T; ++j) b[j] = slab[buf][4 * q + lk][16 * j + li];
@@ -747,7 +748,8 @@ __global__ __launch_bounds__(256) void k_skinny_nn(const amp_t *__restrict__ A, 
 
 template <int T>
 __global__ __launch_bounds__(256) void k_skinny_cn(const amp_t *__restrict__ A, const amp_t *__restrict__ Q,
-                                                  amp_t *__restrict__ Y, uint64_t n, uint64_t m, int l) {
+                                                  amp_t *__restrict__ Y, uint64_t n, uint64_t m, int l,
+                                                  double im_sign) {
     __shared__ amp_t slab[2][SK_SLAB][16 * T];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -802,7 +804,8 @@ __global__ __launch_bounds__(256) void k_skinny_cn(const amp_t *__restrict__ A, 
         for (int b = 0; b < SK_SLAB / 8; ++b)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const double are = a_now[2 * b + h].x, aim = a_now[2 * b + h].y;     // conj(A): (are, -aim)
+                // the MFMAs below take conj(A): (are, -aim); im_sign = -1 turns that into the plain transpose
+                const double are = a_now[2 * b + h].x, aim = im_sign * a_now[2 * b + h].y;
                 amp_t q[T];
 #pragma unroll
                 for (int j = 0; j < T; ++j) q[j] = slab[buf][8 * b + 2 * lk + h][16 * j + li];
@@ -843,22 +846,24 @@ __global__ __launch_bounds__(256) void k_skinny_cn(const amp_t *__restrict__ A, 
     }
 }
 
-// Y = A Q (conj_transpose == 0: A is n x m, Q is m x l, Y is n x l) or Y = A^H Q (A is n x m, Q is n x l, Y is m x l);
-// everything column-major with tight leading dimensions.  Returns false when the shape is outside what the kernels take
-// (l > 64) so that the caller can use the library instead.
-bool skinny_gemm(hipStream_t stream, bool conj_transpose, const amp_t *A, const amp_t *Q, amp_t *Y, uint64_t n,
-                 uint64_t m, int l) {
+// Y = op(A) Q with A (n x m), everything column-major with tight leading dimensions:
+//   transpose == false: Y (n x l) = A Q or conj(A) Q   (Q is m x l);   transpose == true: Y (m x l) = A^T Q or A^H Q   (Q is n x l).
+// Returns false when the shape is outside what the kernels take (l > 64) so that the caller can use the library instead.
+bool skinny_gemm(hipStream_t stream, bool transpose, bool conjugate, const amp_t *A, const amp_t *Q, amp_t *Y,
+                 uint64_t n, uint64_t m, int l) {
     if (l < 1 || l > 64) return false;
     const int tiles = (l + 15) / 16;
-    const uint64_t out_rows = conj_transpose ? m : n;
+    const uint64_t out_rows = transpose ? m : n;
     const unsigned row_blocks = static_cast<unsigned>((out_rows + 63) / 64);
     // one wave per SIMD cannot hide its own load latency: below two workgroups per CU the k range is cut in two
-    const unsigned split = row_blocks < 512 && (conj_transpose ? n : m) >= 4 * SK_SLAB ? 2 : 1;
+    const unsigned split = row_blocks < 512 && (transpose ? n : m) >= 4 * SK_SLAB ? 2 : 1;
     if (split > 1 && hipMemsetAsync(Y, 0, sizeof(amp_t) * out_rows * l, stream) != hipSuccess) return false;
     const dim3 grid(row_blocks, split), block(256);
-#define QSV_SKINNY(T)                                                                                         \
-    if (conj_transpose) hipLaunchKernelGGL(k_skinny_cn<T>, grid, block, 0, stream, A, Q, Y, n, m, l);         \
-    else hipLaunchKernelGGL(k_skinny_nn<T>, grid, block, 0, stream, A, Q, Y, n, m, l)
+    // k_skinny_nn multiplies by (re, im_sign * im); k_skinny_cn by the conjugate of that
+    const double im_sign = transpose ? (conjugate ? 1.0 : -1.0) : (conjugate ? -1.0 : 1.0);
+#define QSV_SKINNY(T)                                                                                              \
+    if (transpose) hipLaunchKernelGGL(k_skinny_cn<T>, grid, block, 0, stream, A, Q, Y, n, m, l, im_sign);          \
+    else hipLaunchKernelGGL(k_skinny_nn<T>, grid, block, 0, stream, A, Q, Y, n, m, l, im_sign)
     switch (tiles) {
         case 1: QSV_SKINNY(1); break;
         case 2: QSV_SKINNY(2); break;
@@ -917,9 +922,9 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
     const uint64_t n = wide ? cols : rows, m = wide ? rows : cols;
     const uint64_t L = static_cast<uint64_t>(l);
     DeviceBuffers buf;
-    buf.reserve(device, sizeof(amp_t) * ((n + m) * (L + static_cast<uint64_t>(k_keep)) + (GRAM_BLOCKS + 4) * L * L +
-                                         (wide ? 0 : n * m)) + 8 * L + 8192);
-    amp_t *A = nullptr, *Qn = nullptr, *Qm = nullptr, *partials = nullptr, *small = nullptr, *UA = nullptr, *VA = nullptr;
+    buf.reserve(device, sizeof(amp_t) * ((n + m) * (L + static_cast<uint64_t>(k_keep)) + (GRAM_BLOCKS + 4) * L * L) + 8 * L +
+                            8192);
+    amp_t *Qn = nullptr, *Qm = nullptr, *partials = nullptr, *small = nullptr, *UA = nullptr, *VA = nullptr;
     double *dS = nullptr;
     // small: r_factor | r_total | U_r | V_r, each L x L
     if (!buf.alloc(&Qn, sizeof(amp_t) * n * L) || !buf.alloc(&Qm, sizeof(amp_t) * m * L) ||
@@ -927,16 +932,10 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
         !buf.alloc(&dS, sizeof(double) * L))
         return qsv_fail(QSV_ENOMEM, "device allocation of the randomized-SVD workspace failed");
     amp_t *r_factor = small, *r_total = small + L * L, *Ur = small + 2 * L * L, *Vr = small + 3 * L * L;
-    if (wide) {
-        A = const_cast<amp_t *>(theta);      // row-major (rows x cols) read column-major is theta^T = A
-    } else {
-        if (!buf.alloc(&A, sizeof(amp_t) * n * m))
-            return qsv_fail(QSV_ENOMEM, "device allocation of the randomized-SVD workspace failed");
-        const uint64_t tiles = ((n + 15) / 16) * ((m + 15) / 16);
-        hipLaunchKernelGGL(k_to_column_major, dim3(static_cast<unsigned>(tiles < 65536 ? tiles : 65536)), dim3(256), 0,
-                           stream, theta, A, n, m);
-        QSV_HIP(hipGetLastError());
-    }
+    // theta is row-major (rows x cols); read column-major it is M = theta^T (cols x rows, ld cols).  The reference works on
+    // the tall orientation A: wide theta -> A = theta^T = M itself; tall theta -> A = theta = M^T, reached through the
+    // transposed / conjugated forms of the panel kernels, so no re-ordered copy of theta is ever made.
+    const amp_t *M = theta;
     const rocblas_double_complex one{1.0, 0.0}, zero{0.0, 0.0};
     auto Z = [](const amp_t *p) { return reinterpret_cast<const rocblas_double_complex *>(p); };
     auto W = [](amp_t *p) { return reinterpret_cast<rocblas_double_complex *>(p); };
@@ -947,12 +946,21 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
                rocblas_status_success;
     };
     const rocblas_operation N = rocblas_operation_none, Cc = rocblas_operation_conjugate_transpose;
-    // the passes over A: the MFMA panel kernels (l tiled by 16), rocBLAS if they decline the shape
+    // the passes over A: the MFMA panel kernels (l tiled by 16); rocBLAS if they decline the shape
+    const rocblas_operation T_ = rocblas_operation_transpose;
+    const rocblas_int ld = static_cast<rocblas_int>(cols);       // leading dimension of M
     auto times_a = [&](const amp_t *panel, amp_t *out) {          // out (n x l) = A panel (m x l)
-        return skinny_gemm(stream, false, A, panel, out, n, m, l) || gemm(N, N, ni, li, mi, A, ni, panel, mi, out, ni);
+        if (wide)   // A = M (n x m)
+            return skinny_gemm(stream, false, false, M, panel, out, n, m, l) ||
+                   gemm(N, N, ni, li, mi, M, ld, panel, mi, out, ni);
+        // A = M^T with M (m x n)
+        return skinny_gemm(stream, true, false, M, panel, out, m, n, l) || gemm(T_, N, ni, li, mi, M, ld, panel, mi, out, ni);
     };
     auto times_ah = [&](const amp_t *panel, amp_t *out) {         // out (m x l) = A^H panel (n x l)
-        return skinny_gemm(stream, true, A, panel, out, n, m, l) || gemm(Cc, N, mi, li, ni, A, ni, panel, ni, out, mi);
+        if (wide) return skinny_gemm(stream, true, true, M, panel, out, n, m, l) ||
+                         gemm(Cc, N, mi, li, ni, M, ld, panel, ni, out, mi);
+        // A^H = conj(M): no library form for a plain conjugate, the kernels take every l <= 64 this path is entered with
+        return skinny_gemm(stream, false, true, M, panel, out, m, n, l);
     };
     bool ok = times_a(omega, Qn);                                                                 // Y = A O
     int rc = ok ? panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr) : QSV_OK;
@@ -1147,10 +1155,11 @@ int qsvg_axis_gemm(int device, hipStream_t stream, const amp_t *in, amp_t *out, 
 }
 
 // Column-major tall-skinny product on the f64 matrix cores (see k_skinny_nn / k_skinny_cn).
-int qsvg_skinny_gemm(int device, hipStream_t stream, int conj_transpose, uint64_t n, uint64_t m, int l, const amp_t *A,
+int qsvg_skinny_gemm(int device, hipStream_t stream, int op, uint64_t n, uint64_t m, int l, const amp_t *A,
                      const amp_t *Q, amp_t *Y) {
     QSV_HIP(hipSetDevice(device));
-    if (!skinny_gemm(stream, conj_transpose != 0, A, Q, Y, n, m, l))
+    // op: 0 = A, 1 = A^H, 2 = A^T, 3 = conj(A)
+    if (!skinny_gemm(stream, op == 1 || op == 2, op == 1 || op == 3, A, Q, Y, n, m, l))
         return qsv_fail(QSV_EINVAL, "panel width must be 1..64 columns");
     return QSV_OK;
 }

@@ -129,7 +129,7 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
 int qsvg_rsvd_split(int device, hipStream_t stream, const amp_t *theta, uint64_t rows, uint64_t cols, int64_t k_keep,
                     int l, int q, const amp_t *omega, double abs_err, double rel_err, amp_t *m1, amp_t *m2,
                     uint64_t capacity, uint64_t *rank_out, double *s_host);
-int qsvg_skinny_gemm(int device, hipStream_t stream, int conj_transpose, uint64_t n, uint64_t m, int l, const amp_t *A,
+int qsvg_skinny_gemm(int device, hipStream_t stream, int op, uint64_t n, uint64_t m, int l, const amp_t *A,
                      const amp_t *Q, amp_t *Y);
 int qsvq_tensor_scale_axis(int device, hipStream_t stream, amp_t *t, uint64_t L, uint64_t d, uint64_t R,
                            const double *dev_diag);

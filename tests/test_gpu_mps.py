@@ -126,8 +126,8 @@ def test_library_qr_path_of_the_randomized_split_still_works():
 @pytest.mark.parametrize("n,m,l", [(100, 70, 5), (257, 129, 16), (1000, 333, 26), (2049, 515, 42), (130, 1027, 64),
                                    (64, 32, 1), (4096, 4096, 33)])
 def test_mfma_tall_skinny_products(n, m, l):
-    """``qsv_tensor_skinny_gemm``: Y = A Q and Y = A^H Q (column-major) on the f64 matrix cores, ragged shapes, with and
-    without the split of the k range."""
+    """``qsv_tensor_skinny_gemm``: Y = op(A) Q for op in {A, A^H, A^T, conj A} (column-major) on the f64 matrix cores,
+    ragged shapes, with and without the split of the k range."""
     import ctypes as C
 
     import torch
@@ -137,15 +137,17 @@ def test_mfma_tall_skinny_products(n, m, l):
     a = rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m))
     dev_a = torch.from_numpy(np.ascontiguousarray(a.T)).cuda()             # row-major A^T == column-major A
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for conj, rows_q, rows_y in ((0, m, n), (1, n, m)):
+    forms = {0: lambda x: x, 1: lambda x: x.conj().T, 2: lambda x: x.T, 3: lambda x: x.conj()}
+    for op, form in forms.items():
+        rows_q, rows_y = (n, m) if op in (1, 2) else (m, n)
         q = rng.standard_normal((rows_q, l)) + 1j * rng.standard_normal((rows_q, l))
         dev_q = torch.from_numpy(np.ascontiguousarray(q.T)).cuda()
         dev_y = torch.empty(l, rows_y, dtype=torch.complex128, device="cuda")
-        _lib.call("qsv_tensor_skinny_gemm", 0, stream, conj, n, m, l, C.c_void_p(dev_a.data_ptr()),
+        _lib.call("qsv_tensor_skinny_gemm", 0, stream, op, n, m, l, C.c_void_p(dev_a.data_ptr()),
                   C.c_void_p(dev_q.data_ptr()), C.c_void_p(dev_y.data_ptr()))
         torch.cuda.synchronize()
-        want = (a.conj().T if conj else a) @ q
-        assert maxdiff(dev_y.cpu().numpy().T, want) < 1e-12 * np.abs(want).max()
+        want = form(a) @ q
+        assert maxdiff(dev_y.cpu().numpy().T, want) < 1e-12 * np.abs(want).max(), op
     with pytest.raises(ValueError):
         _lib.call("qsv_tensor_skinny_gemm", 0, stream, 0, n, m, 65, C.c_void_p(dev_a.data_ptr()),
                   C.c_void_p(dev_a.data_ptr()), C.c_void_p(dev_a.data_ptr()))
