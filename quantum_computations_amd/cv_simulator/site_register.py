@@ -54,6 +54,7 @@ class SiteRegister:
         self.d = int(d)
         self.sites = [self._upload(np.asarray(s).reshape(1, -1, 1) if np.ndim(s) == 1 else s) for s in sites]
         self._resident: OrderedDict[int, tuple] = OrderedDict()    # host operator id -> (host array, device copy)
+        self._scratch_buffers: dict = {}
         self.last_singular_values: np.ndarray | None = None
         self.split_counts = {"exact": 0, "randomized": 0}          # which branch of tensor_svd the splits took
 
@@ -66,6 +67,20 @@ class SiteRegister:
     def _empty(self, *shape):
         torch = _torch()
         return torch.empty(shape, dtype=torch.complex128, device=self._dev)
+
+    def _scratch(self, slot: str, *shape):
+        """A complex128 tensor of ``shape`` carved from this register's persistent scratch buffer ``slot`` (grow-only).
+        The two-site temporaries (theta, its mapped image, the capacity-sized split outputs) are gigabytes at the
+        reference's sizes and die within the gate: re-using one buffer per role keeps hipMalloc / hipFree -- which
+        synchronise the device -- out of the gate loop."""
+        torch = _torch()
+        count = int(np.prod(shape))
+        held = self._scratch_buffers.get(slot)
+        if held is None or held.numel() < count:
+            self._scratch_buffers.pop(slot, None)
+            held = torch.empty(count + count // 8, dtype=torch.complex128, device=self._dev)
+            self._scratch_buffers[slot] = held
+        return held[:count].view(*shape)
 
     def _stream(self) -> C.c_void_p:
         torch = _torch()
@@ -88,8 +103,8 @@ class SiteRegister:
     def _p(t) -> C.c_void_p:
         return C.c_void_p(t.data_ptr())
 
-    def _gemm(self, a, op_a: int, b, op_b: int, m: int, n: int, k: int):
-        out = self._empty(m, n)
+    def _gemm(self, a, op_a: int, b, op_b: int, m: int, n: int, k: int, scratch: str | None = None):
+        out = self._scratch(scratch, m, n) if scratch else self._empty(m, n)
         _lib.call("qsv_tensor_gemm", self.device, self._stream(), op_a, op_b, m, n, k, self._p(a), self._p(b),
                   self._p(out))
         return out
@@ -111,6 +126,7 @@ class SiteRegister:
     def close(self) -> None:
         self.sites = []
         self._resident.clear()
+        self._scratch_buffers.clear()
 
     def copy(self) -> "SiteRegister":
         out = SiteRegister([], self.d, self.device)
@@ -198,7 +214,7 @@ class SiteRegister:
         a, b = self.sites[left], self.sites[left + 1]
         cl, d, chi = (int(x) for x in a.shape)
         cr = int(b.shape[2])
-        theta = self._gemm(a, OP_NONE, b, OP_NONE, cl * d, d * cr, chi)
+        theta = self._gemm(a, OP_NONE, b, OP_NONE, cl * d, d * cr, chi, scratch="theta")
         return theta, cl, d, cr
 
     def _split(self, theta, rows: int, cols: int, *, max_bond_dim=np.inf, abs_err: float = 0, rel_err: float = 1e-12,
@@ -209,7 +225,7 @@ class SiteRegister:
         full = min(rows, cols)
         capped = np.isfinite(max_bond_dim)
         cap = max(0, min(full, int(max_bond_dim))) if capped else full
-        m1, m2 = self._empty(rows, max(cap, 1)), self._empty(max(cap, 1), cols)
+        m1, m2 = self._scratch("m1", rows, max(cap, 1)), self._scratch("m2", max(cap, 1), cols)
         rank = C.c_uint64(0)
         if capped and max_bond_dim * 10 < full and cap >= 1:
             k = int(max_bond_dim)
@@ -258,7 +274,7 @@ class SiteRegister:
         per_point = int(cols.shape[-1]) if cols.ndim > 1 else 1
         dev_cols = self._keep(cols, np.int32)
         dev_vals = self._keep(weights, np.complex128)
-        mapped = self._empty(cl * d, d * cr)
+        mapped = self._scratch("mapped", cl * d, d * cr)
         _lib.call("qsv_tensor_plane_gather", self.device, self._stream(), self._p(theta), self._p(mapped), cl, d, cr,
                   per_point, self._p(dev_cols), self._p(dev_vals))
         m1, m2, r = self._split(mapped, cl * d, d * cr, **truncation)
@@ -275,7 +291,7 @@ class SiteRegister:
     def apply_plane_affine(self, grid: np.ndarray, coefficients, left: int, **truncation) -> None:
         """BS / CX: resample every plane at ``(a00 x + a01 y, a10 x + a11 y)``, bilinear, computed in the kernel."""
         theta, cl, d, cr = self._two_site(left)
-        mapped = self._empty(cl * d, d * cr)
+        mapped = self._scratch("mapped", cl * d, d * cr)
         a = (C.c_double * 4)(*[float(v) for v in coefficients])
         _lib.call("qsv_tensor_plane_affine", self.device, self._stream(), self._p(theta), self._p(mapped), cl, d, cr,
                   self._p(self._keep(grid, np.float64)), a)
@@ -311,7 +327,7 @@ class SiteRegister:
         t = self.sites[mode]
         cl, d, cr = (int(x) for x in t.shape)
         dev_vec = self._upload(vec)
-        joined = self._empty(cl * d, d * cr)                      # [a, i, (j, b)] = vec[i] * t[a, (j, b)]
+        joined = self._scratch("theta", cl * d, d * cr)          # [a, i, (j, b)] = vec[i] * t[a, (j, b)]
         _lib.call("qsv_tensor_insert_axis", self.device, self._stream(), self._p(t), self._p(joined), cl, d, d * cr,
                   self._p(dev_vec))
         m1, m2, r = self._split(joined, cl * d, d * cr, **truncation)
@@ -320,7 +336,7 @@ class SiteRegister:
 
     # ---- GKP layer (gkp_simulator) ----------------------------------------------------------------------------
     def _outer(self, p, q, x: int, y: int, z: int, w: int, swap_last: bool):
-        out = self._empty(x * y, z * w)
+        out = self._scratch("theta", x * y, z * w)
         _lib.call("qsv_tensor_outer", self.device, self._stream(), self._p(p), self._p(q), self._p(out), x, y, z, w,
                   int(swap_last))
         return out
