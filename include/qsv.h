@@ -213,6 +213,9 @@ int qsv_tensor_rsvd_split(int device, void *hip_stream, const void *dev_theta, u
  * transposed / conjugated forms let a row-major theta be used in either orientation without a re-ordered copy. */
 int qsv_tensor_skinny_gemm(int device, void *hip_stream, int op, uint64_t n, uint64_t m, int l, const void *dev_a,
                            const void *dev_q, void *dev_y);
+/* The splits keep their scratch memory (a copy-free pass needs panels only, the exact SVD its factors) in a grow-only
+ * pool per device; this returns the pool of `device` to the driver.  It is re-grown on demand. */
+int qsv_tensor_release_workspace(int device);
 /* t[l, j, r] *= diag[j] in place: Z and P on a site (gates.py:223,245). */
 int qsv_tensor_scale_axis(int device, void *hip_stream, void *dev_t, uint64_t L, uint64_t d, uint64_t R,
                           const void *dev_diag /* d */);

@@ -76,6 +76,7 @@ SIGNATURES: dict[str, list] = {
     "qsv_tensor_rsvd_split": [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double,
                               C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p],
     "qsv_tensor_skinny_gemm": [C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    "qsv_tensor_release_workspace": [C.c_int],
     "qsv_tensor_scale_axis": [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p],
     "qsv_tensor_plane_diag": [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p],
     "qsv_tensor_plane_gather": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p],

@@ -797,6 +797,8 @@ int qsv_tensor_skinny_gemm(int device, void *hip_stream, int op, uint64_t n, uin
     return qsvg_skinny_gemm(device, as_stream(hip_stream), op, n, m, l, camp(dev_a), camp(dev_q), amp(dev_y));
 }
 
+int qsv_tensor_release_workspace(int device) { return qsvg_release_workspace(device); }
+
 int qsv_tensor_scale_axis(int device, void *hip_stream, void *dev_t, uint64_t L, uint64_t d, uint64_t R,
                           const void *dev_diag) {
     if (!dev_t || !dev_diag) return qsv_fail(QSV_EINVAL, "null pointer");

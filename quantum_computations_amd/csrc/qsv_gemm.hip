@@ -1163,3 +1163,19 @@ int qsvg_skinny_gemm(int device, hipStream_t stream, int op, uint64_t n, uint64_
         return qsv_fail(QSV_EINVAL, "panel width must be 1..64 columns");
     return QSV_OK;
 }
+
+// Give the decomposition scratch pool of `device` back to the driver (it is re-grown on demand).
+int qsvg_release_workspace(int device) {
+    if (device < 0 || device >= 16) return qsv_fail(QSV_EINVAL, "device index out of range");
+    RocblasApi &a = api();
+    std::lock_guard<std::mutex> guard(a.lock);
+    Pool &pool = pool_of(device);
+    if (pool.base) {
+        QSV_HIP(hipSetDevice(device));
+        QSV_HIP(hipDeviceSynchronize());
+        QSV_HIP(hipFree(pool.base));
+        pool.base = nullptr;
+        pool.capacity = 0;
+    }
+    return QSV_OK;
+}

@@ -131,6 +131,7 @@ int qsvg_rsvd_split(int device, hipStream_t stream, const amp_t *theta, uint64_t
                     uint64_t capacity, uint64_t *rank_out, double *s_host);
 int qsvg_skinny_gemm(int device, hipStream_t stream, int op, uint64_t n, uint64_t m, int l, const amp_t *A,
                      const amp_t *Q, amp_t *Y);
+int qsvg_release_workspace(int device);
 int qsvq_tensor_scale_axis(int device, hipStream_t stream, amp_t *t, uint64_t L, uint64_t d, uint64_t R,
                            const double *dev_diag);
 int qsvq_tensor_plane_diag(int device, hipStream_t stream, amp_t *t, uint64_t L, uint64_t d, uint64_t R,

@@ -127,6 +127,7 @@ class SiteRegister:
         self.sites = []
         self._resident.clear()
         self._scratch_buffers.clear()
+        _lib.call("qsv_tensor_release_workspace", self.device)
 
     def copy(self) -> "SiteRegister":
         out = SiteRegister([], self.d, self.device)
