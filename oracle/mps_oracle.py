@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY — NumPy restatement of the reference's matrix-product-state update (cv_simulator).
 
-Only ``tests/``, ``__graft_entry__.smoke()`` and the CPU-baseline legs of the benchmarks may import this module; the
-product (``quantum_computations_amd``) never does.
+Only ``tests/`` (parity tests and ``tests/bench_mps.py``, whose CPU leg is this module) may import it; the product
+(``quantum_computations_amd``) never does.
 
 What is restated, with the reference lines each piece follows:
 

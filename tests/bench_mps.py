@@ -7,7 +7,7 @@ CPU: ``oracle.mps_oracle.Chain`` (the NumPy restatement of the reference, pinned
 of the same circuit with the same random stream, timed on the host cores; norms, bond dimensions and position
 marginals of the two runs are compared at the end of that prefix.
 
-    python tools/bench_mps.py [--d 1000] [--modes 4] [--bond 16] [--layers 2] [--cpu-gates 12] [--out FILE]
+    python tests/bench_mps.py [--d 1000] [--modes 4] [--bond 16] [--layers 2] [--cpu-gates 12] [--out FILE]
 """
 from __future__ import annotations
 
@@ -22,7 +22,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT / "tests"))        # mps_driver (this file lives under tests/ because it runs the CPU oracle)
 
 
 def program(cv, State, modes: int, layers: int, options: dict):
