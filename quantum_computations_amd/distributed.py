@@ -172,7 +172,15 @@ class ShardedState:
         send_r, recv_r = torch.view_as_real(send), torch.view_as_real(recv)
         if self.multipath and self.world >= 4 and send.numel() % self.world == 0:
             mask = self.rank ^ peer
-            dist.all_to_all_single(recv_r, send_r, group=self.group)        # phase 1: chunk y -> rank y
+            try:
+                dist.all_to_all_single(recv_r, send_r, group=self.group)    # phase 1: chunk y -> rank y
+            except (RuntimeError, TypeError, ValueError, NotImplementedError) as exc:
+                # a backend that rejects the collective does so while validating its arguments -- before anything is
+                # sent, and identically on every rank -- so all ranks fall back to the direct transfer together
+                import warnings
+                warnings.warn(f"all_to_all_single unavailable ({exc}); using direct send/recv for qubit exchanges")
+                self.multipath = False
+                return self._exchange(send, recv, peer)
             relay = recv_r.view(self.world, -1)
             staged = send_r.view(self.world, -1)
             order = torch.tensor([z ^ mask for z in range(self.world)], device=send.device)
