@@ -653,7 +653,7 @@ template <int T>                      // T = number of 16-column tiles of the pa
 __global__ __launch_bounds__(256) void k_skinny_nn(const amp_t *__restrict__ A, const amp_t *__restrict__ Q,
                                                   amp_t *__restrict__ Y, uint64_t n, uint64_t m, int l,
                                                   double im_sign) {
-    __shared__ amp_t slab[2][SK_SLAB][16 * T];
+    __shared__ amp_t slab[2][SK_SLAB][16 * T + 1];   // +1: the column-wise slab stores would otherwise hit one bank
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const uint64_t row = static_cast<uint64_t>(blockIdx.x) * 64 + wave * 16 + li;
@@ -750,7 +750,7 @@ template <int T>
 __global__ __launch_bounds__(256) void k_skinny_cn(const amp_t *__restrict__ A, const amp_t *__restrict__ Q,
                                                   amp_t *__restrict__ Y, uint64_t n, uint64_t m, int l,
                                                   double im_sign) {
-    __shared__ amp_t slab[2][SK_SLAB][16 * T];
+    __shared__ amp_t slab[2][SK_SLAB][16 * T + 1];   // +1: the column-wise slab stores would otherwise hit one bank
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const uint64_t col = static_cast<uint64_t>(blockIdx.x) * 64 + wave * 16 + li;   // column of A = output row
