@@ -28,6 +28,7 @@ struct RocblasApi {
     decltype(&rocblas_set_stream) set_stream = nullptr;
     decltype(&rocblas_zgemm_strided_batched) zgemm = nullptr;
     decltype(&rocsolver_zgesvd) zgesvd = nullptr;      // null when rocSOLVER is absent: SVD entry points fail loudly
+    decltype(&rocsolver_zgesdd) zgesdd = nullptr;
     decltype(&rocsolver_zgeqrf) zgeqrf = nullptr;
     decltype(&rocsolver_zungqr) zungqr = nullptr;
     rocblas_handle handle[16] = {};
@@ -65,6 +66,7 @@ bool load_locked(RocblasApi &a) {
         }
         if (solver) {
             a.zgesvd = reinterpret_cast<decltype(a.zgesvd)>(dlsym(solver, "rocsolver_zgesvd"));
+            a.zgesdd = reinterpret_cast<decltype(a.zgesdd)>(dlsym(solver, "rocsolver_zgesdd"));
             a.zgeqrf = reinterpret_cast<decltype(a.zgeqrf)>(dlsym(solver, "rocsolver_zgeqrf"));
             a.zungqr = reinterpret_cast<decltype(a.zungqr)>(dlsym(solver, "rocsolver_zungqr"));
         }
@@ -536,12 +538,15 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_scale_strided_conj(const amp_t *_
 }
 
 // The reference's truncation rule (mps.py:83-86) on singular values sorted in decreasing order.
-uint64_t kept_rank(const std::vector<double> &sv, int64_t max_bond_dim, double abs_err, double rel_err) {
+double allowed_error(const std::vector<double> &sv, double abs_err, double rel_err) {
     double total = 0.0;
     for (double v : sv) total += v;
     double allowed = total * rel_err;
     if (abs_err > allowed) allowed = abs_err;
-    if (allowed < 0.0) allowed = 0.0;
+    return allowed < 0.0 ? 0.0 : allowed;
+}
+
+uint64_t kept_rank_for(const std::vector<double> &sv, int64_t max_bond_dim, double allowed) {
     uint64_t r = 0;
     double tail = 0.0;
     for (size_t i = sv.size(); i-- > 0;) {
@@ -551,6 +556,10 @@ uint64_t kept_rank(const std::vector<double> &sv, int64_t max_bond_dim, double a
     if (max_bond_dim >= 0 && r > static_cast<uint64_t>(max_bond_dim)) r = static_cast<uint64_t>(max_bond_dim);
     if (r > sv.size()) r = sv.size();
     return r;
+}
+
+uint64_t kept_rank(const std::vector<double> &sv, int64_t max_bond_dim, double abs_err, double rel_err) {
+    return kept_rank_for(sv, max_bond_dim, allowed_error(sv, abs_err, rel_err));
 }
 
 }  // namespace
@@ -579,6 +588,12 @@ int qsvg_gemm(int device, hipStream_t stream, int op_a, int op_b, uint64_t m, ui
     return QSV_OK;
 }
 
+constexpr int QSV_UNDECIDED = 2;
+bool fused_panels_enabled();
+int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream_t stream, const amp_t *theta,
+                          uint64_t rows, uint64_t cols, int64_t max_bond_dim, double abs_err, double rel_err, amp_t *m1,
+                          amp_t *m2, uint64_t capacity, uint64_t *rank_out, std::vector<double> *values);
+
 // tensor_svd (cv_simulator/mps.py:52-97) of a row-major (rows x cols) device matrix:
 //   theta = U S Vh,  r from the truncation rule,  m1 = U[:, :r] sqrt(S[:r]),  m2 = sqrt(S[:r]) Vh[:r, :].
 // rocSOLVER is column-major, so it factors theta^T = U' S V'^H (cols x rows); then U = (V'^H)^T and Vh = U'^T, i.e.
@@ -595,8 +610,23 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
     if (!h) return rc;
     if (!a.zgesvd) return qsv_fail(QSV_EHIP, "rocSOLVER could not be loaded (librocsolver.so.0): no SVD available");
     const uint64_t k = rows < cols ? rows : cols;
+    static const bool shortcuts_enabled = [] {
+        const char *v = std::getenv("QSV_SVD");
+        return !(v && std::string(v) == "exact");
+    }();
+    if (shortcuts_enabled && fused_panels_enabled() && (rel_err >= 1e-4 || abs_err > 0.0)) {
+        std::vector<double> values;
+        const int fast = try_verified_low_rank(a, h, device, stream, theta, rows, cols, max_bond_dim, abs_err, rel_err, m1, m2,
+                                               capacity, rank_out, s_host ? &values : nullptr);
+        if (fast == QSV_OK) {
+            if (s_host)
+                for (uint64_t i = 0; i < k; ++i) s_host[i] = values[i];
+            return QSV_OK;
+        }
+        if (fast != QSV_UNDECIDED) return fast;
+    }
     DeviceBuffers buf;
-    buf.reserve(device, sizeof(amp_t) * (cols * k + k * rows) + 16 * k + 4096);
+    buf.reserve(device, sizeof(amp_t) * (cols * k + k * rows + rows * cols) + 16 * k + 8192);
     double *dS = nullptr, *dE = nullptr;
     amp_t *dU = nullptr, *dV = nullptr;
     rocblas_int *dinfo = nullptr;
@@ -604,19 +634,55 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
         !buf.alloc(&dU, sizeof(amp_t) * cols * k) || !buf.alloc(&dV, sizeof(amp_t) * k * rows) ||
         !buf.alloc(&dinfo, sizeof(rocblas_int)))
         return qsv_fail(QSV_ENOMEM, "device allocation of the SVD factors failed");
-    const rocblas_status s = a.zgesvd(
-        h, rocblas_svect_singular, rocblas_svect_singular, static_cast<rocblas_int>(cols),
-        static_cast<rocblas_int>(rows), reinterpret_cast<rocblas_double_complex *>(theta),
-        static_cast<rocblas_int>(cols), dS, reinterpret_cast<rocblas_double_complex *>(dU),
-        static_cast<rocblas_int>(cols), reinterpret_cast<rocblas_double_complex *>(dV), static_cast<rocblas_int>(k), dE,
-        rocblas_outofplace, dinfo);
-    if (s != rocblas_status_success) return qsv_fail(QSV_EHIP, "rocsolver_zgesvd failed");
     std::vector<double> sv(k);
     rocblas_int info = 0;
-    QSV_HIP(hipMemcpyAsync(sv.data(), dS, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
-    QSV_HIP(hipMemcpyAsync(&info, dinfo, sizeof(info), hipMemcpyDeviceToHost, stream));
-    QSV_HIP(hipStreamSynchronize(stream));
-    if (info != 0) return qsv_fail(QSV_EHIP, "rocsolver_zgesvd did not converge");
+    const rocblas_int ci = static_cast<rocblas_int>(cols), ri = static_cast<rocblas_int>(rows), ki = static_cast<rocblas_int>(k);
+    auto Zp = [](amp_t *p) { return reinterpret_cast<rocblas_double_complex *>(p); };
+    auto fetch_values = [&]() -> int {
+        QSV_HIP(hipMemcpyAsync(sv.data(), dS, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+        QSV_HIP(hipMemcpyAsync(&info, dinfo, sizeof(info), hipMemcpyDeviceToHost, stream));
+        QSV_HIP(hipStreamSynchronize(stream));
+        return QSV_OK;
+    };
+    // rocSOLVER's zgesvd needs seconds on the graded spectra of these matrices (5 s at 2000 x 2000); its zgesdd goes
+    // through the eigenvectors of A^H A and takes 0.17 s, but that route cannot resolve singular values below
+    // ~1e-8 sigma_max.  It is used when the truncation cannot notice: the allowed error must exceed the possible
+    // garbage in the tail sum by a wide margin, the kept rank must be the same at both ends of that margin, and every
+    // kept value must be well above the floor; otherwise theta is restored and zgesvd decides.
+    bool decided = false;
+    static const bool gram_route_enabled = [] {
+        const char *v = std::getenv("QSV_SVD");
+        return !(v && std::string(v) == "exact");
+    }();
+    if (a.zgesdd && gram_route_enabled && (rel_err >= 1e-6 || abs_err > 0.0)) {
+        amp_t *backup = nullptr;
+        if (buf.alloc(&backup, sizeof(amp_t) * rows * cols)) {
+            QSV_HIP(hipMemcpyAsync(backup, theta, sizeof(amp_t) * rows * cols, hipMemcpyDeviceToDevice, stream));
+            if (a.zgesdd(h, rocblas_svect_singular, rocblas_svect_singular, ci, ri, Zp(theta), ci, dS, Zp(dU), ci, Zp(dV), ki,
+                         dinfo) == rocblas_status_success) {
+                const int rc_fetch = fetch_values();
+                if (rc_fetch) return rc_fetch;
+                if (info == 0 && k > 0) {
+                    const double floor_value = 2e-8 * sv[0], margin = floor_value * static_cast<double>(k);
+                    const double allowed = allowed_error(sv, abs_err, rel_err);
+                    if (allowed > 100.0 * margin) {
+                        const uint64_t r_lo = kept_rank_for(sv, max_bond_dim, allowed + margin);
+                        const uint64_t r_hi = kept_rank_for(sv, max_bond_dim, allowed - margin);
+                        decided = r_lo == r_hi && (r_lo == 0 || sv[r_lo - 1] > 1e3 * floor_value);
+                    }
+                }
+            }
+            if (!decided) QSV_HIP(hipMemcpyAsync(theta, backup, sizeof(amp_t) * rows * cols, hipMemcpyDeviceToDevice, stream));
+        }
+    }
+    if (!decided) {
+        const rocblas_status s = a.zgesvd(h, rocblas_svect_singular, rocblas_svect_singular, ci, ri, Zp(theta), ci, dS, Zp(dU),
+                                          ci, Zp(dV), ki, dE, rocblas_outofplace, dinfo);
+        if (s != rocblas_status_success) return qsv_fail(QSV_EHIP, "rocsolver_zgesvd failed");
+        const int rc_fetch = fetch_values();
+        if (rc_fetch) return rc_fetch;
+        if (info != 0) return qsv_fail(QSV_EHIP, "rocsolver_zgesvd did not converge");
+    }
     const uint64_t r = kept_rank(sv, max_bond_dim, abs_err, rel_err);
     if (r > capacity) return qsv_fail(QSV_EINVAL, "output buffers are smaller than the kept bond dimension");
     if (r > 0) {
@@ -915,9 +981,21 @@ bool fused_panels_enabled() {
 
 // The randomized split with the fused panel kernels: same algorithm and random stream as below, but every
 // re-orthonormalisation is 9 launches and the l x m projection is decomposed through B^H = Qb Rb and a Jacobi SVD of Rb.
+// `verify` != null switches to the *verified low-rank* mode used by the exact split (see qsvg_svd_split): all l computed
+// values are examined, the Frobenius norm of what the l-dimensional projection misses is known exactly
+// (||A||_F^2 - sum sigma~_i^2), and the split is accepted only if the truncation rule provably gives the same rank as it
+// would on the full spectrum; the function returns QSV_UNDECIDED otherwise and theta is untouched.
+struct LowRankCheck {
+    double frobenius_squared;   // ||theta||_F^2
+    int64_t max_bond_dim;       // the caller's cap (k_keep only bounds what the projection may return)
+    uint64_t full_rank;         // min(rows, cols)
+    std::vector<double> *values;   // out: the kept spectrum padded with zeros to full_rank
+};
+
 int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t stream, const amp_t *theta, uint64_t rows,
                      uint64_t cols, int64_t k_keep, int l, int q, const amp_t *omega, double abs_err, double rel_err,
-                     amp_t *m1, amp_t *m2, uint64_t capacity, uint64_t *rank_out, double *s_host) {
+                     amp_t *m1, amp_t *m2, uint64_t capacity, uint64_t *rank_out, double *s_host,
+                     const LowRankCheck *verify = nullptr) {
     const bool wide = rows < cols;
     const uint64_t n = wide ? cols : rows, m = wide ? rows : cols;
     const uint64_t L = static_cast<uint64_t>(l);
@@ -977,11 +1055,38 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
     if (rc) return rc;
     hipLaunchKernelGGL(k_small_svd, dim3(1), dim3(256), 0, stream, r_total, l, Ur, dS, Vr);
     QSV_HIP(hipGetLastError());
-    const uint64_t k = static_cast<uint64_t>(k_keep);
+    const uint64_t k = verify ? L : static_cast<uint64_t>(k_keep);
     std::vector<double> sv(k);
     QSV_HIP(hipMemcpyAsync(sv.data(), dS, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
     QSV_HIP(hipStreamSynchronize(stream));
-    const uint64_t r = kept_rank(sv, k_keep, abs_err, rel_err);
+    uint64_t r;
+    if (verify) {
+        // What the projection misses: rho^2 = ||A||_F^2 - sum sigma~_i^2 = ||(I - Q Q^H) A||_F^2 exactly, so every true
+        // singular value differs from its computed counterpart by at most rho, and the uncaptured ones sum to at most
+        // sqrt(full - l) rho.  rho itself is resolved down to ~1e-8 ||A|| (it is a difference of squares).
+        double captured = 0.0;
+        for (double v : sv) captured += v * v;
+        const double f2 = verify->frobenius_squared;
+        double rho2 = f2 - captured;
+        const double resolution = 4e-16 * static_cast<double>(L) * f2;
+        if (rho2 < resolution) rho2 = resolution;
+        const double rho = sqrt(rho2), missing = sqrt(static_cast<double>(verify->full_rank - L)) * rho;
+        const double margin = (static_cast<double>(L) * rho + missing) * (1.0 + rel_err);
+        const double allowed = allowed_error(sv, abs_err, rel_err);
+        if (!(allowed > 100.0 * margin)) return QSV_UNDECIDED;
+        const uint64_t r_lo = kept_rank_for(sv, verify->max_bond_dim, allowed + margin);
+        const uint64_t r_hi = kept_rank_for(sv, verify->max_bond_dim, allowed - margin);
+        // the kept triplets must sit well inside the captured block and far above what was missed
+        if (r_lo != r_hi || r_lo > static_cast<uint64_t>(k_keep) || (r_lo > 0 && !(sv[r_lo - 1] > 1e3 * rho)))
+            return QSV_UNDECIDED;
+        r = r_lo;
+        if (verify->values) {
+            verify->values->assign(verify->full_rank, 0.0);
+            for (uint64_t i = 0; i < L && i < verify->full_rank; ++i) (*verify->values)[i] = sv[i];
+        }
+    } else {
+        r = kept_rank(sv, k_keep, abs_err, rel_err);
+    }
     if (r > capacity) return qsv_fail(QSV_EINVAL, "output buffers are smaller than the kept bond dimension");
     if (r > 0) {
         const rocblas_int ri = static_cast<rocblas_int>(r);
@@ -1000,10 +1105,68 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
         QSV_HIP(hipGetLastError());
     }
     QSV_HIP(hipStreamSynchronize(stream));   // the workspace is freed on return
-    if (s_host)
+    if (s_host && !verify)
         for (uint64_t i = 0; i < k; ++i) s_host[i] = sv[i];
     *rank_out = r;
     return QSV_OK;
+}
+
+// sum of |x|^2 over `count` amplitudes into per-block partials
+__global__ __launch_bounds__(256) void k_sum_squares(const amp_t *__restrict__ x, uint64_t count, double *__restrict__ partials) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < count; i += gridDim.x * 256ull) s += x[i].x * x[i].x + x[i].y * x[i].y;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// The exact split's shortcut for numerically low-rank theta under a loose tolerance (the regime of the reference's own
+// GKP runs: rel_err = 1e-2, bonds of 1-2 on d = 1000 grids, where LAPACK-style SVDs of 1000..2000-sized matrices are all
+// the time there is): a 64-probe range finder with its own fixed random stream -- the reference's exact branch draws no
+// random numbers, so the caller's generator must not be touched -- verified a posteriori by LowRankCheck.
+int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream_t stream, const amp_t *theta,
+                          uint64_t rows, uint64_t cols, int64_t max_bond_dim, double abs_err, double rel_err, amp_t *m1,
+                          amp_t *m2, uint64_t capacity, uint64_t *rank_out, std::vector<double> *values) {
+    const uint64_t full = rows < cols ? rows : cols;
+    const int l = LMAX, keep = LMAX - 10;
+    if (full < 4 * static_cast<uint64_t>(l)) return QSV_UNDECIDED;       // small matrices: the library SVD is cheap
+    DeviceBuffers buf;                                                  // omega and the norm partials: not from the pool,
+    amp_t *omega = nullptr;                                             // which rsvd_split_fused carves for itself
+    double *partials = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&omega), sizeof(amp_t) * full * l) != hipSuccess) return QSV_UNDECIDED;
+    buf.extra[buf.n++] = omega;
+    if (hipMalloc(reinterpret_cast<void **>(&partials), sizeof(double) * 256) != hipSuccess) return QSV_UNDECIDED;
+    buf.extra[buf.n++] = partials;
+    static std::vector<double> host;                                     // the probe matrix, rebuilt when the size changes
+    const bool rebuild = host.size() != 2 * full * l;
+    if (rebuild) host.assign(2 * full * l, 0.0);
+    uint64_t state = 0x9e3779b97f4a7c15ull;                              // splitmix64 + Box-Muller: a fixed probe matrix
+    auto next = [&]() {
+        state += 0x9e3779b97f4a7c15ull;
+        uint64_t z = state;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return ((z ^ (z >> 31)) >> 11) * (1.0 / 9007199254740992.0);
+    };
+    for (uint64_t i = 0; rebuild && i < full * l; ++i) {
+        const double u1 = next() + 1e-300, u2 = next();
+        host[2 * i] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        host[2 * i + 1] = 0.0;
+    }
+    QSV_HIP(hipMemcpyAsync(omega, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_sum_squares, dim3(256), dim3(256), 0, stream, theta, rows * cols, partials);
+    QSV_HIP(hipGetLastError());
+    double sums[256];
+    QSV_HIP(hipMemcpyAsync(sums, partials, sizeof(sums), hipMemcpyDeviceToHost, stream));
+    QSV_HIP(hipStreamSynchronize(stream));
+    LowRankCheck check{0.0, max_bond_dim, full, values};
+    for (double v : sums) check.frobenius_squared += v;
+    if (!(check.frobenius_squared > 0.0)) return QSV_UNDECIDED;
+    return rsvd_split_fused(a, h, device, stream, theta, rows, cols, keep, l, 7, omega, abs_err, rel_err, m1, m2, capacity,
+                            rank_out, nullptr, &check);
 }
 
 // tensor_svd on its randomized branch (mps.py:5-50,78-79; Halko, Martinsson & Tropp 2010): range finder with
@@ -1031,6 +1194,25 @@ int qsvg_rsvd_split(int device, hipStream_t stream, const amp_t *theta, uint64_t
     if (L <= LMAX && fused_panels_enabled())
         return rsvd_split_fused(a, h, device, stream, theta, rows, cols, k_keep, l, q, omega, abs_err, rel_err, m1, m2, capacity,
                                 rank_out, s_host);
+    // More probes than the fused kernels take (max_bond_dim > 54, e.g. the 100 of the reference's GKP runs).  Under a
+    // loose tolerance the kept rank is far below that anyway: the verified low-rank route decides it with 64 probes of
+    // its own; the caller has already drawn -- and thereby consumed from its generator -- the test matrix the reference
+    // would use, so the random stream of a seeded simulation is unaffected.
+    static const bool shortcuts_enabled = [] {
+        const char *v = std::getenv("QSV_SVD");
+        return !(v && std::string(v) == "exact");
+    }();
+    if (shortcuts_enabled && fused_panels_enabled() && (rel_err >= 1e-4 || abs_err > 0.0)) {
+        std::vector<double> values;
+        const int fast = try_verified_low_rank(a, h, device, stream, theta, rows, cols, k_keep, abs_err, rel_err, m1, m2,
+                                               capacity, rank_out, s_host ? &values : nullptr);
+        if (fast == QSV_OK) {
+            if (s_host)
+                for (int64_t i = 0; i < k_keep; ++i) s_host[i] = values[static_cast<size_t>(i)];
+            return QSV_OK;
+        }
+        if (fast != QSV_UNDECIDED) return fast;
+    }
     DeviceBuffers buf;
     buf.reserve(device, sizeof(amp_t) * ((n + m) * L + L + L * m + L * kk + kk * m + n * static_cast<uint64_t>(k_keep) +
                                          (wide ? 0 : n * m)) + 16 * kk + 8192);

@@ -151,3 +151,25 @@ def test_mfma_tall_skinny_products(n, m, l):
     with pytest.raises(ValueError):
         _lib.call("qsv_tensor_skinny_gemm", 0, stream, 0, n, m, 65, C.c_void_p(dev_a.data_ptr()),
                   C.c_void_p(dev_a.data_ptr()), C.c_void_p(dev_a.data_ptr()))
+
+
+@pytest.mark.parametrize("shape", [(700, 520), (300, 1100), (1024, 1024)])
+@pytest.mark.parametrize("options", [{"rel_err": 1e-2}, {"rel_err": 1e-3, "max_bond_dim": 40}, {"abs_err": 5e-3, "rel_err": 0.0},
+                                     {"rel_err": 1e-5}])
+def test_exact_split_shortcuts_keep_the_reference_rank(shape, options):
+    """Under loose tolerances the exact branch of ``tensor_svd`` may be served by the verified low-rank route or by
+    rocSOLVER's Gram-based ``zgesdd`` instead of ``zgesvd`` (see qsvg_svd_split): the kept rank must be the one the
+    truncation rule gives on LAPACK's spectrum, and the product must match the exactly truncated one."""
+    from oracle import mps_oracle as MO
+    rng = np.random.default_rng(shape[0] + shape[1])
+    rows, cols = shape
+    full = min(rows, cols)
+    u, _ = np.linalg.qr(rng.standard_normal((rows, full)) + 1j * rng.standard_normal((rows, full)))
+    v, _ = np.linalg.qr(rng.standard_normal((cols, full)) + 1j * rng.standard_normal((cols, full)))
+    spectrum = np.exp(-np.arange(full) / 6.0) + 1e-9 * rng.random(full)       # graded, with a noise floor
+    a = (u * spectrum) @ v.conj().T
+    want1, want2 = MO.split(a, **options)
+    m1, m2 = tensor_svd(a.reshape(rows, 1, 1, cols), [0, 1], [2, 3], **options)
+    assert m1.shape[-1] == want1.shape[1]
+    got = np.tensordot(m1, m2, axes=1).reshape(rows, cols)
+    assert maxdiff(got, want1 @ want2) < 1e-9

@@ -3,7 +3,7 @@
 qubit circuit -> layered gadgets -> CV gates on the matrix-product register -> Pauli frame + logical density matrix,
 and the fidelity of the frame-corrected logical state with the ideal qubit simulation of the same circuit.
 
-    python tools/bench_gkp.py [--d 1000] [--db 12] [--bond 32] [--seed 1] [--out FILE]
+    python tools/bench_gkp.py [--d 1000] [--db 12] [--bond 32] [--rel-err 1e-10] [--seed 1] [--out FILE]
 """
 from __future__ import annotations
 
@@ -25,6 +25,7 @@ def main() -> None:
     ap.add_argument("--half-width", type=float, default=20.0)
     ap.add_argument("--db", type=float, default=12.0)
     ap.add_argument("--bond", type=int, default=32)
+    ap.add_argument("--rel-err", type=float, default=1e-10)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -41,7 +42,7 @@ def main() -> None:
     circuit = [dv.H(0), dv.H(1), dv.CZ(0, 1), dv.T(1), dv.H(1), dv.CZ(1, 2), dv.P(2), dv.H(0), dv.SWAP(0, 1), dv.T(0)]
     inputs = [State.ZERO, State.PLUS, State.ZERO]
     layered = MBGKPCircuit.transpile(circuit)
-    options = {"max_bond_dim": args.bond, "rel_err": 1e-10}
+    options = {"max_bond_dim": args.bond, "rel_err": args.rel_err}
 
     def run(seed):
         sim = Simulator(layered, eps, rng_seed=seed, svd_options=options)
@@ -64,7 +65,7 @@ def main() -> None:
     corrected = syndrome_matrix(frame) @ rho @ syndrome_matrix(frame).conj().T
     fidelity = float(np.real(np.vdot(ket, corrected @ ket)))
     result = {"workload": f"MB-GKP, 3 qubits, {len(circuit)} logical gates in {layered.depth()} layers "
-                          f"({layered.count()} gadgets), d={args.d}, {args.db} dB, max_bond_dim={args.bond}",
+                          f"({layered.count()} gadgets), d={args.d}, {args.db} dB, max_bond_dim={args.bond}, rel_err={args.rel_err:g}",
               "seconds": seconds, "gadgets_per_second": layered.count() / seconds,
               "logical_readout_seconds": readout_seconds, "frame": [list(p) for p in frame],
               "bond_dims": out.reg.bond_dims(),
