@@ -207,7 +207,7 @@ int qsv_tensor_rsvd_split(int device, void *hip_stream, const void *dev_theta, u
                           double abs_err, double rel_err, void *dev_m1, void *dev_m2, uint64_t capacity,
                           uint64_t *rank, double *singular_values /* max_bond_dim doubles or NULL */);
 /* Tall-skinny product on the f64 matrix cores, COLUMN-major with tight leading dimensions: Y = op(A) . Q with A (n x m)
- * and a panel of 1 <= l <= 64 columns; op: 0 = A, 3 = conj(A) (Q is m x l, Y is n x l); 1 = A^H, 2 = A^T (Q is n x l,
+ * and a panel of 1 <= l <= 256 columns (one pass over A per 64 of them); op: 0 = A, 3 = conj(A) (Q is m x l, Y is n x l); 1 = A^H, 2 = A^T (Q is n x l,
  * Y is m x l).  The building block of the range finder (A @ O, A^H @ Q, A @ Q of mps.py:15-21), where A is gigabytes
  * and the panel a few dozen columns: l is tiled in steps of 16 instead of the library's 64-wide macro tile, and the
  * transposed / conjugated forms let a row-major theta be used in either orientation without a re-ordered copy. */

@@ -11,6 +11,7 @@
 // kernels; `QSV_NO_ROCBLAS=1` forces that for comparisons.
 #include <dlfcn.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -915,11 +916,21 @@ __global__ __launch_bounds__(256) void k_skinny_cn(const amp_t *__restrict__ A, 
 // Y = op(A) Q with A (n x m), everything column-major with tight leading dimensions:
 //   transpose == false: Y (n x l) = A Q or conj(A) Q   (Q is m x l);   transpose == true: Y (m x l) = A^T Q or A^H Q   (Q is n x l).
 // Returns false when the shape is outside what the kernels take (l > 64) so that the caller can use the library instead.
+constexpr int WIDE_MAX = 256;        // widest panel the blocked (64-column) forms take
+
 bool skinny_gemm(hipStream_t stream, bool transpose, bool conjugate, const amp_t *A, const amp_t *Q, amp_t *Y,
                  uint64_t n, uint64_t m, int l) {
-    if (l < 1 || l > 64) return false;
-    const int tiles = (l + 15) / 16;
+    if (l < 1 || l > WIDE_MAX) return false;
     const uint64_t out_rows = transpose ? m : n;
+    if (l > 64) {        // panels wider than the kernels' 64 columns: one pass over A per 64-column slice
+        const uint64_t q_rows = transpose ? n : m;
+        for (int c0 = 0; c0 < l; c0 += 64)
+            if (!skinny_gemm(stream, transpose, conjugate, A, Q + static_cast<uint64_t>(c0) * q_rows,
+                             Y + static_cast<uint64_t>(c0) * out_rows, n, m, l - c0 < 64 ? l - c0 : 64))
+                return false;
+        return true;
+    }
+    const int tiles = (l + 15) / 16;
     const unsigned row_blocks = static_cast<unsigned>((out_rows + 63) / 64);
     // one wave per SIMD cannot hide its own load latency: below two workgroups per CU the k range is cut in two
     const unsigned split = row_blocks < 512 && (transpose ? n : m) >= 4 * SK_SLAB ? 2 : 1;
@@ -971,12 +982,164 @@ int panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t 
     return QSV_OK;
 }
 
+// ---- panels wider than 64 columns: block Gram-Schmidt over 64-column blocks -------------------------------------------
+// partials[block][i * lb + j] = sum over the block's rows of conj(Ya[r, i]) * Yb[r, j]  (two panels of la, lb <= 64 columns)
+__global__ __launch_bounds__(256) void k_panel_cross(const amp_t *__restrict__ Ya, const amp_t *__restrict__ Yb,
+                                                    uint64_t n, int la, int lb, amp_t *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    amp_t *ta = reinterpret_cast<amp_t *>(smem_raw);     // [la][PANEL_PITCH]
+    amp_t *tb = ta + la * PANEL_PITCH;                   // [lb][PANEL_PITCH]
+    const int t = threadIdx.x, entries = la * lb;
+    amp_t acc[LMAX * LMAX / 256];
+#pragma unroll
+    for (int k = 0; k < LMAX * LMAX / 256; ++k) acc[k] = amp_t{0.0, 0.0};
+    for (uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * PANEL_ROWS; r0 < n;
+         r0 += static_cast<uint64_t>(gridDim.x) * PANEL_ROWS) {
+        __syncthreads();
+        for (int idx = t; idx < (la + lb) * PANEL_ROWS; idx += 256) {
+            const int c = idx / PANEL_ROWS, r = idx % PANEL_ROWS;
+            const amp_t *src = c < la ? Ya + static_cast<uint64_t>(c) * n : Yb + static_cast<uint64_t>(c - la) * n;
+            ta[c * PANEL_PITCH + r] = r0 + r < n ? src[r0 + r] : amp_t{0.0, 0.0};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LMAX * LMAX / 256; ++k) {
+            const int e = t + 256 * k;
+            if (e < entries) {
+                const amp_t *ci = ta + (e / lb) * PANEL_PITCH, *cj = tb + (e % lb) * PANEL_PITCH;
+                amp_t a = acc[k];
+                for (int r = 0; r < PANEL_ROWS; ++r) {
+                    const amp_t p = conj_mul(ci[r], cj[r]);
+                    a.x += p.x;
+                    a.y += p.y;
+                }
+                acc[k] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LMAX * LMAX / 256; ++k) {
+        const int e = t + 256 * k;
+        if (e < entries) partials[static_cast<size_t>(blockIdx.x) * entries + e] = acc[k];
+    }
+}
+
+// C (la x lb, row-major) = sum of the partials; optionally R[row0 + i][col0 + j] (+)= C[i][j] in the l x l factor
+__global__ __launch_bounds__(256) void k_cross_reduce(const amp_t *__restrict__ partials, int nblocks, int la, int lb,
+                                                     amp_t *__restrict__ C, amp_t *__restrict__ R, int l, int row0,
+                                                     int col0, int accumulate) {
+    const int entries = la * lb;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < entries; e += gridDim.x * 256) {
+        amp_t s = {0.0, 0.0};
+        for (int b = 0; b < nblocks; ++b) {
+            const amp_t v = partials[static_cast<size_t>(b) * entries + e];
+            s.x += v.x;
+            s.y += v.y;
+        }
+        C[e] = s;
+        if (R) {
+            amp_t *dst = R + static_cast<size_t>(row0 + e / lb) * l + col0 + e % lb;
+            *dst = accumulate ? amp_t{dst->x + s.x, dst->y + s.y} : s;
+        }
+    }
+}
+
+// Yb[r, j] -= sum_i Qa[r, i] * C[i][j]   (Qa: la columns, Yb: lb columns, C row-major la x lb)
+__global__ __launch_bounds__(256) void k_panel_update(amp_t *__restrict__ Yb, const amp_t *__restrict__ Qa, uint64_t n,
+                                                     int la, int lb, const amp_t *__restrict__ C) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    amp_t *tile = reinterpret_cast<amp_t *>(smem_raw);   // [la][PANEL_PITCH]
+    amp_t *Cs = tile + la * PANEL_PITCH;                 // [la][lb]
+    const int t = threadIdx.x, r = t % PANEL_ROWS, group = t / PANEL_ROWS;
+    for (int e = t; e < la * lb; e += 256) Cs[e] = C[e];
+    for (uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * PANEL_ROWS; r0 < n;
+         r0 += static_cast<uint64_t>(gridDim.x) * PANEL_ROWS) {
+        __syncthreads();
+        for (int idx = t; idx < la * PANEL_ROWS; idx += 256) {
+            const int c = idx / PANEL_ROWS, rr = idx % PANEL_ROWS;
+            tile[c * PANEL_PITCH + rr] = r0 + rr < n ? Qa[static_cast<uint64_t>(c) * n + r0 + rr] : amp_t{0.0, 0.0};
+        }
+        __syncthreads();
+        if (r0 + r < n)
+            for (int j = group; j < lb; j += 256 / PANEL_ROWS) {
+                amp_t acc = Yb[static_cast<uint64_t>(j) * n + r0 + r];
+                for (int i = 0; i < la; ++i) {
+                    const amp_t p = plain_mul(tile[i * PANEL_PITCH + r], Cs[i * lb + j]);
+                    acc.x -= p.x;
+                    acc.y -= p.y;
+                }
+                Yb[static_cast<uint64_t>(j) * n + r0 + r] = acc;
+            }
+    }
+}
+
+// out[row0 + i][col0 + j] = src[i][j] for an (h x w) row-major block `src` inside the l x l row-major `out`
+__global__ __launch_bounds__(256) void k_place_block(amp_t *__restrict__ out, int l, int row0, int col0,
+                                                    const amp_t *__restrict__ src, int h, int w) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < h * w; e += gridDim.x * 256)
+        out[static_cast<size_t>(row0 + e / w) * l + col0 + e % w] = src[e];
+}
+
+// Orthonormalise a column-major (n x l) panel of any width up to WIDE_MAX: shifted CholeskyQR3 on 64-column blocks, each
+// first projected twice against the blocks before it (block classical Gram-Schmidt with re-orthogonalisation).
+// `r_total` (l x l row-major, may be null) receives the block upper triangular factor with Y_in = Y_out * r_total;
+// `scratch` holds 2 * 64 * 64 amplitudes.
+int wide_panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t *partials, amp_t *scratch,
+                              amp_t *r_total) {
+    if (l <= LMAX && !r_total) return panel_orthonormalise(stream, Y, n, l, partials, scratch, nullptr);
+    if (l <= LMAX) return panel_orthonormalise(stream, Y, n, l, partials, scratch, r_total);
+    static bool raised = false;
+    if (!raised) {
+        const int big = static_cast<int>((2 * LMAX * PANEL_PITCH) * sizeof(amp_t));
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_panel_cross), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_panel_update), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>((LMAX * PANEL_PITCH + LMAX * LMAX) * sizeof(amp_t))));
+        raised = true;
+    }
+    amp_t *block_factor = scratch, *cross = scratch + LMAX * LMAX;
+    const uint64_t tiles = (n + PANEL_ROWS - 1) / PANEL_ROWS;
+    const int red_blocks = static_cast<int>(tiles < GRAM_BLOCKS ? tiles : GRAM_BLOCKS);
+    const unsigned row_blocks = static_cast<unsigned>(tiles < 4096 ? tiles : 4096);
+    if (r_total) QSV_HIP(hipMemsetAsync(r_total, 0, sizeof(amp_t) * l * l, stream));
+    for (int c0 = 0; c0 < l; c0 += LMAX) {
+        const int w = l - c0 < LMAX ? l - c0 : LMAX;
+        amp_t *Yj = Y + static_cast<uint64_t>(c0) * n;
+        for (int pass = 0; pass < 2 && c0 > 0; ++pass)
+            for (int p0 = 0; p0 < c0; p0 += LMAX) {
+                const amp_t *Qi = Y + static_cast<uint64_t>(p0) * n;        // earlier blocks are full 64-column blocks
+                hipLaunchKernelGGL(k_panel_cross, dim3(red_blocks), dim3(256), sizeof(amp_t) * (LMAX + w) * PANEL_PITCH,
+                                   stream, Qi, Yj, n, LMAX, w, partials);
+                hipLaunchKernelGGL(k_cross_reduce, dim3(4), dim3(256), 0, stream, partials, red_blocks, LMAX, w, cross,
+                                   r_total, l, p0, c0, 1);
+                hipLaunchKernelGGL(k_panel_update, dim3(row_blocks), dim3(256),
+                                   sizeof(amp_t) * (LMAX * PANEL_PITCH + LMAX * w), stream, Yj, Qi, n, LMAX, w, cross);
+            }
+        // the block itself; its triangular factor goes on the diagonal of r_total
+        amp_t *diag = r_total ? cross : nullptr;       // w x w, row-major, reuses the cross buffer
+        const int rc = panel_orthonormalise(stream, Yj, n, w, partials, block_factor, diag);
+        if (rc) return rc;
+        if (r_total) hipLaunchKernelGGL(k_place_block, dim3(4), dim3(256), 0, stream, r_total, l, c0, c0, diag, w, w);
+    }
+    QSV_HIP(hipGetLastError());
+    return QSV_OK;
+}
+
 bool fused_panels_enabled() {
     static const bool on = [] {
         const char *v = std::getenv("QSV_RSVD");
         return !(v && std::string(v) == "rocsolver");
     }();
     return on;
+}
+
+// out (column-major l x l) = transpose of in (column-major l x l);  conjugate != 0: out = conj(in) elementwise instead
+__global__ __launch_bounds__(256) void k_small_reorder(const amp_t *__restrict__ in, amp_t *__restrict__ out, int l,
+                                                      int conjugate) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < l * l; e += gridDim.x * 256) {
+        const int i = e % l, k = e / l;
+        const amp_t v = conjugate ? in[e] : in[static_cast<size_t>(i) * l + k];
+        out[e] = conjugate ? amp_t{v.x, -v.y} : v;
+    }
 }
 
 // The randomized split with the fused panel kernels: same algorithm and random stream as below, but every
@@ -1000,16 +1163,17 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
     const uint64_t n = wide ? cols : rows, m = wide ? rows : cols;
     const uint64_t L = static_cast<uint64_t>(l);
     DeviceBuffers buf;
-    buf.reserve(device, sizeof(amp_t) * ((n + m) * (L + static_cast<uint64_t>(k_keep)) + (GRAM_BLOCKS + 4) * L * L) + 8 * L +
-                            8192);
+    const uint64_t block = L < LMAX ? L : LMAX, scratch_amps = 2 * LMAX * LMAX;
+    buf.reserve(device, sizeof(amp_t) * ((n + m) * (L + static_cast<uint64_t>(k_keep)) + GRAM_BLOCKS * block * block +
+                                         scratch_amps + 5 * L * L) + 32 * L + 16384);
     amp_t *Qn = nullptr, *Qm = nullptr, *partials = nullptr, *small = nullptr, *UA = nullptr, *VA = nullptr;
     double *dS = nullptr;
-    // small: r_factor | r_total | U_r | V_r, each L x L
+    // small: block scratch (2 x 64 x 64) | r_total | U_r | V_r | library scratch, each L x L
     if (!buf.alloc(&Qn, sizeof(amp_t) * n * L) || !buf.alloc(&Qm, sizeof(amp_t) * m * L) ||
-        !buf.alloc(&partials, sizeof(amp_t) * GRAM_BLOCKS * L * L) || !buf.alloc(&small, sizeof(amp_t) * 4 * L * L) ||
-        !buf.alloc(&dS, sizeof(double) * L))
+        !buf.alloc(&partials, sizeof(amp_t) * GRAM_BLOCKS * block * block) ||
+        !buf.alloc(&small, sizeof(amp_t) * (scratch_amps + 5 * L * L)) || !buf.alloc(&dS, sizeof(double) * (2 * L + 2)))
         return qsv_fail(QSV_ENOMEM, "device allocation of the randomized-SVD workspace failed");
-    amp_t *r_factor = small, *r_total = small + L * L, *Ur = small + 2 * L * L, *Vr = small + 3 * L * L;
+    amp_t *r_factor = small, *r_total = small + scratch_amps, *Ur = r_total + L * L, *Vr = Ur + L * L, *lib = Vr + L * L;
     // theta is row-major (rows x cols); read column-major it is M = theta^T (cols x rows, ld cols).  The reference works on
     // the tall orientation A: wide theta -> A = theta^T = M itself; tall theta -> A = theta = M^T, reached through the
     // transposed / conjugated forms of the panel kernels, so no re-ordered copy of theta is ever made.
@@ -1041,24 +1205,44 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
         return skinny_gemm(stream, false, true, M, panel, out, m, n, l);
     };
     bool ok = times_a(omega, Qn);                                                                 // Y = A O
-    int rc = ok ? panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr) : QSV_OK;
+    int rc = ok ? wide_panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr) : QSV_OK;
     for (int it = 0; ok && !rc && it < q; ++it) {
         ok = times_ah(Qn, Qm);                                                                    // Y = A^H Q
-        if (ok) rc = panel_orthonormalise(stream, Qm, m, l, partials, r_factor, nullptr);
+        if (ok) rc = wide_panel_orthonormalise(stream, Qm, m, l, partials, r_factor, nullptr);
         ok = ok && !rc && times_a(Qm, Qn);                                                        // Y = A Q
-        if (ok) rc = panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr);
+        if (ok) rc = wide_panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr);
     }
     // B^H = A^H Q = Qb Rb  (m x l);  Rb = Ur S Vr^H;  A ~ (Q Vr) S (Qb Ur)^H
     ok = ok && !rc && times_ah(Qn, Qm);
-    if (ok) rc = panel_orthonormalise(stream, Qm, m, l, partials, r_factor, r_total);
+    if (ok) rc = wide_panel_orthonormalise(stream, Qm, m, l, partials, r_factor, r_total);
     if (!ok) return qsv_fail(QSV_EHIP, "rocBLAS call failed in the randomized range finder");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_small_svd, dim3(1), dim3(256), 0, stream, r_total, l, Ur, dS, Vr);
-    QSV_HIP(hipGetLastError());
+    if (L <= LMAX) {
+        hipLaunchKernelGGL(k_small_svd, dim3(1), dim3(256), 0, stream, r_total, l, Ur, dS, Vr);
+        QSV_HIP(hipGetLastError());
+    } else {
+        // wider than the one-workgroup Jacobi kernel: the library decomposes the l x l factor.  r_total is row-major, i.e.
+        // X = R^T column-major; X = U' S V'^H gives R = conj(V') S U'^T, so U_r = (V'^H)^T and V_r = conj(U').
+        if (!a.zgesvd) return qsv_fail(QSV_EHIP, "rocSOLVER could not be loaded (librocsolver.so.0): no SVD available");
+        amp_t *Uprime = lib, *Vh = lib + L * L;     // lib has 2 L^2: U' and V'^H
+        double *dE = dS + L;
+        rocblas_int *dinfo = reinterpret_cast<rocblas_int *>(dS + 2 * L);
+        if (a.zgesvd(h, rocblas_svect_singular, rocblas_svect_singular, li, li, W(r_total), li, dS, W(Uprime), li, W(Vh), li, dE,
+                     rocblas_outofplace, dinfo) != rocblas_status_success)
+            return qsv_fail(QSV_EHIP, "rocsolver_zgesvd failed");
+        hipLaunchKernelGGL(k_small_reorder, dim3(16), dim3(256), 0, stream, Vh, Ur, l, 0);
+        hipLaunchKernelGGL(k_small_reorder, dim3(16), dim3(256), 0, stream, Uprime, Vr, l, 1);
+        QSV_HIP(hipGetLastError());
+    }
     const uint64_t k = verify ? L : static_cast<uint64_t>(k_keep);
     std::vector<double> sv(k);
+    rocblas_int svd_info = 0;
     QSV_HIP(hipMemcpyAsync(sv.data(), dS, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+    if (L > LMAX)
+        QSV_HIP(hipMemcpyAsync(&svd_info, reinterpret_cast<rocblas_int *>(dS + 2 * L), sizeof(svd_info), hipMemcpyDeviceToHost,
+                               stream));
     QSV_HIP(hipStreamSynchronize(stream));
+    if (svd_info != 0) return qsv_fail(QSV_EHIP, "rocsolver_zgesvd did not converge on the projected factor");
     uint64_t r;
     if (verify) {
         // What the projection misses: rho^2 = ||A||_F^2 - sum sigma~_i^2 = ||(I - Q Q^H) A||_F^2 exactly, so every true
@@ -1073,9 +1257,17 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
         const double rho = sqrt(rho2), missing = sqrt(static_cast<double>(verify->full_rank - L)) * rho;
         const double margin = (static_cast<double>(L) * rho + missing) * (1.0 + rel_err);
         const double allowed = allowed_error(sv, abs_err, rel_err);
-        if (!(allowed > 100.0 * margin)) return QSV_UNDECIDED;
+        static const bool trace = std::getenv("QSV_TRACE_SPLIT") != nullptr;
+        if (trace)
+            fprintf(stderr, "[qsv split] %llu x %llu: probes %d, ||A||_F %.3e, rho %.3e, allowed %.3e, margin %.3e, s0 %.3e\n",
+                    static_cast<unsigned long long>(rows), static_cast<unsigned long long>(cols), l, sqrt(f2), rho, allowed,
+                    margin, sv[0]);
+        if (!(allowed > 2.0 * margin)) return QSV_UNDECIDED;
         const uint64_t r_lo = kept_rank_for(sv, verify->max_bond_dim, allowed + margin);
         const uint64_t r_hi = kept_rank_for(sv, verify->max_bond_dim, allowed - margin);
+        if (trace)
+            fprintf(stderr, "[qsv split]   r in [%llu, %llu], s[r-1] %.3e\n", static_cast<unsigned long long>(r_lo),
+                    static_cast<unsigned long long>(r_hi), r_lo > 0 ? sv[r_lo - 1] : 0.0);
         // the kept triplets must sit well inside the captured block and far above what was missed
         if (r_lo != r_hi || r_lo > static_cast<uint64_t>(k_keep) || (r_lo > 0 && !(sv[r_lo - 1] > 1e3 * rho)))
             return QSV_UNDECIDED;
@@ -1131,7 +1323,7 @@ int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream
                           uint64_t rows, uint64_t cols, int64_t max_bond_dim, double abs_err, double rel_err, amp_t *m1,
                           amp_t *m2, uint64_t capacity, uint64_t *rank_out, std::vector<double> *values) {
     const uint64_t full = rows < cols ? rows : cols;
-    const int l = LMAX, keep = LMAX - 10;
+    const int l = LMAX, keep = l - 10;          // one 64-column block of probes: everything stays in the fused kernels
     if (full < 4 * static_cast<uint64_t>(l)) return QSV_UNDECIDED;       // small matrices: the library SVD is cheap
     DeviceBuffers buf;                                                  // omega and the norm partials: not from the pool,
     amp_t *omega = nullptr;                                             // which rsvd_split_fused carves for itself
@@ -1202,7 +1394,7 @@ int qsvg_rsvd_split(int device, hipStream_t stream, const amp_t *theta, uint64_t
         const char *v = std::getenv("QSV_SVD");
         return !(v && std::string(v) == "exact");
     }();
-    if (shortcuts_enabled && fused_panels_enabled() && (rel_err >= 1e-4 || abs_err > 0.0)) {
+    if (L > LMAX && shortcuts_enabled && fused_panels_enabled() && (rel_err >= 1e-4 || abs_err > 0.0)) {
         std::vector<double> values;
         const int fast = try_verified_low_rank(a, h, device, stream, theta, rows, cols, k_keep, abs_err, rel_err, m1, m2,
                                                capacity, rank_out, s_host ? &values : nullptr);
@@ -1213,6 +1405,9 @@ int qsvg_rsvd_split(int device, hipStream_t stream, const amp_t *theta, uint64_t
         }
         if (fast != QSV_UNDECIDED) return fast;
     }
+    if (L <= WIDE_MAX && fused_panels_enabled())      // 64-column blocks of probes, library SVD of the projected factor
+        return rsvd_split_fused(a, h, device, stream, theta, rows, cols, k_keep, l, q, omega, abs_err, rel_err, m1, m2, capacity,
+                                rank_out, s_host);
     DeviceBuffers buf;
     buf.reserve(device, sizeof(amp_t) * ((n + m) * L + L + L * m + L * kk + kk * m + n * static_cast<uint64_t>(k_keep) +
                                          (wide ? 0 : n * m)) + 16 * kk + 8192);
@@ -1342,7 +1537,7 @@ int qsvg_skinny_gemm(int device, hipStream_t stream, int op, uint64_t n, uint64_
     QSV_HIP(hipSetDevice(device));
     // op: 0 = A, 1 = A^H, 2 = A^T, 3 = conj(A)
     if (!skinny_gemm(stream, op == 1 || op == 2, op == 1 || op == 3, A, Q, Y, n, m, l))
-        return qsv_fail(QSV_EINVAL, "panel width must be 1..64 columns");
+        return qsv_fail(QSV_EINVAL, "panel width must be 1..256 columns");
     return QSV_OK;
 }
 

@@ -124,7 +124,7 @@ def test_library_qr_path_of_the_randomized_split_still_works():
 
 
 @pytest.mark.parametrize("n,m,l", [(100, 70, 5), (257, 129, 16), (1000, 333, 26), (2049, 515, 42), (130, 1027, 64),
-                                   (64, 32, 1), (4096, 4096, 33)])
+                                   (64, 32, 1), (4096, 4096, 33), (700, 450, 110), (333, 900, 200)])
 def test_mfma_tall_skinny_products(n, m, l):
     """``qsv_tensor_skinny_gemm``: Y = op(A) Q for op in {A, A^H, A^T, conj A} (column-major) on the f64 matrix cores,
     ragged shapes, with and without the split of the k range."""
@@ -149,7 +149,7 @@ def test_mfma_tall_skinny_products(n, m, l):
         want = form(a) @ q
         assert maxdiff(dev_y.cpu().numpy().T, want) < 1e-12 * np.abs(want).max(), op
     with pytest.raises(ValueError):
-        _lib.call("qsv_tensor_skinny_gemm", 0, stream, 0, n, m, 65, C.c_void_p(dev_a.data_ptr()),
+        _lib.call("qsv_tensor_skinny_gemm", 0, stream, 0, n, m, 257, C.c_void_p(dev_a.data_ptr()),
                   C.c_void_p(dev_a.data_ptr()), C.c_void_p(dev_a.data_ptr()))
 
 
@@ -173,3 +173,21 @@ def test_exact_split_shortcuts_keep_the_reference_rank(shape, options):
     assert m1.shape[-1] == want1.shape[1]
     got = np.tensordot(m1, m2, axes=1).reshape(rows, cols)
     assert maxdiff(got, want1 @ want2) < 1e-9
+
+
+@pytest.mark.parametrize("rows,cols,cap", [(1500, 1300, 70), (1000, 2100, 90), (2600, 2600, 150)])
+def test_randomized_split_with_wide_panels(rows, cols, cap):
+    """max_bond_dim > 54 means more than 64 probe columns: the panels are orthonormalised in 64-column blocks (block
+    Gram-Schmidt around CholeskyQR3) and the projected factor goes to the library SVD.  Same random stream as the
+    reference's randomized branch, so the product must agree with the CPU restatement."""
+    from oracle import mps_oracle as MO
+    rng = np.random.default_rng(rows + cap)
+    full = min(rows, cols)
+    assert cap * 10 < full
+    u, _ = np.linalg.qr(rng.standard_normal((rows, full)) + 1j * rng.standard_normal((rows, full)))
+    v, _ = np.linalg.qr(rng.standard_normal((cols, full)) + 1j * rng.standard_normal((cols, full)))
+    a = (u * np.exp(-np.arange(full) / 9.0)) @ v.conj().T
+    want1, want2 = MO.split(a, max_bond_dim=cap, rng_seed=17)
+    m1, m2 = tensor_svd(a.reshape(rows, 1, 1, cols), [0, 1], [2, 3], max_bond_dim=cap, rng_seed=17)
+    assert m1.shape[-1] == want1.shape[1]
+    assert maxdiff(np.tensordot(m1, m2, axes=1).reshape(rows, cols), want1 @ want2) < 1e-9
