@@ -26,6 +26,9 @@ def main() -> None:
     ap.add_argument("--db", type=float, default=12.0)
     ap.add_argument("--bond", type=int, default=32)
     ap.add_argument("--rel-err", type=float, default=1e-10)
+    ap.add_argument("--circuit", choices=["mix", "grover27"], default="mix",
+                    help="grover27: the reference's headline experiment -- one Grover iteration on 3 GKP qubits with the "
+                         "oracle tagging |010> and |111> (grover.py:37-52), identity gadgets on idle qubits")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -39,9 +42,21 @@ def main() -> None:
 
     qs = np.linspace(-args.half_width, args.half_width, args.d)
     eps = db2eps(args.db)
-    circuit = [dv.H(0), dv.H(1), dv.CZ(0, 1), dv.T(1), dv.H(1), dv.CZ(1, 2), dv.P(2), dv.H(0), dv.SWAP(0, 1), dv.T(0)]
-    inputs = [State.ZERO, State.PLUS, State.ZERO]
+    if args.circuit == "grover27":
+        from quantum_computations_amd import workloads as W
+        circuit = []
+        for gate in W.to_gates(W.grover3_ops([2, 7])[3:]):          # the three Inserts become the initial register
+            if isinstance(gate, dv.CX):                             # CX = H(target) CZ H(target), as grover.py:43-50
+                circuit += [dv.H(gate.target), dv.CZ(*gate.indices), dv.H(gate.target)]
+            else:
+                circuit.append(gate)
+        inputs = [State.ZERO] * 3
+    else:
+        circuit = [dv.H(0), dv.H(1), dv.CZ(0, 1), dv.T(1), dv.H(1), dv.CZ(1, 2), dv.P(2), dv.H(0), dv.SWAP(0, 1), dv.T(0)]
+        inputs = [State.ZERO, State.PLUS, State.ZERO]
     layered = MBGKPCircuit.transpile(circuit)
+    if args.circuit == "grover27":
+        layered.fill()
     options = {"max_bond_dim": args.bond, "rel_err": args.rel_err}
 
     def run(seed):
@@ -64,12 +79,17 @@ def main() -> None:
         ket = gate.apply(ket)
     corrected = syndrome_matrix(frame) @ rho @ syndrome_matrix(frame).conj().T
     fidelity = float(np.real(np.vdot(ket, corrected @ ket)))
-    result = {"workload": f"MB-GKP, 3 qubits, {len(circuit)} logical gates in {layered.depth()} layers "
+    tagged = {"grover27": [2, 7]}.get(args.circuit)
+    success = None if tagged is None else {"gkp": float(sum(np.real(corrected[i, i]) for i in tagged)),
+                                           "ideal": float(sum(abs(ket[i]) ** 2 for i in tagged))}
+    result = {"workload": f"MB-GKP ({args.circuit}), 3 qubits, {len(circuit)} logical gates in {layered.depth()} layers "
                           f"({layered.count()} gadgets), d={args.d}, {args.db} dB, max_bond_dim={args.bond}, rel_err={args.rel_err:g}",
               "seconds": seconds, "gadgets_per_second": layered.count() / seconds,
               "logical_readout_seconds": readout_seconds, "frame": [list(p) for p in frame],
               "bond_dims": out.reg.bond_dims(),
               "logical_fidelity_vs_ideal_circuit": fidelity, "split_counts": out.reg.split_counts}
+    if success is not None:
+        result["grover_success_probability"] = success
     line = json.dumps(result)
     print(line)
     if args.out:
