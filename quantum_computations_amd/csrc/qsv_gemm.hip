@@ -243,7 +243,8 @@ __device__ __forceinline__ amp_t plain_mul(amp_t a, amp_t b) {
 
 // partials[block][i * l + j] = sum over the block's rows of conj(Y[r, i]) * Y[r, j]   (Y column-major, ld n)
 __global__ __launch_bounds__(256) void k_panel_gram(const amp_t *__restrict__ Y, uint64_t n, int l,
-                                                   amp_t *__restrict__ partials) {
+                                                   amp_t *__restrict__ partials, const int *__restrict__ settled) {
+    if (settled && *settled) return;     // the previous round found the panel orthonormal already
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     amp_t *tile = reinterpret_cast<amp_t *>(smem_raw);   // [l][PANEL_PITCH]
     const int t = threadIdx.x, entries = l * l;
@@ -286,8 +287,16 @@ __global__ __launch_bounds__(256) void k_panel_gram(const amp_t *__restrict__ Y,
 __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ partials, int nblocks, int l,
                                                      uint64_t rows, int first_round,
                                                      const amp_t *__restrict__ r_prev, amp_t *__restrict__ r_total,
-                                                     amp_t *__restrict__ r_out) {
+                                                     amp_t *__restrict__ r_out, const int *__restrict__ skip,
+                                                     int *__restrict__ settled) {
+    // `settled` (read by the NEXT round as its `skip`): set when this round's Gram matrix is the identity to 1e-7 -- after
+    // this round's own normalisation the panel is orthonormal to rounding, so every kernel of the next round returns at once
+    if (skip && *skip) {
+        if (settled && threadIdx.x == 0) *settled = 1;
+        return;
+    }
     __shared__ amp_t G[LMAX * LMAX];
+    __shared__ double deviation[4];
     __shared__ amp_t Stage[LMAX * LMAX];
     __shared__ double pivot_floor, shift;
     __shared__ int absent[LMAX];
@@ -323,7 +332,19 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
         shift = first_round ? 11.0 * (static_cast<double>(rows) * l + static_cast<double>(l) * (l + 1)) * u * trace : 0.0;
         pivot_floor = first_round ? 0.0 : static_cast<double>(l) * u * top;
     }
+    if (settled) {
+        double dev = first_round ? 1.0 : 0.0;      // the shifted round never settles anything
+        for (int e = t; e < entries; e += 256) {
+            const int i = e / l, k = e % l;
+            if (k >= i) dev = fmax(dev, fmax(fabs(G[e].x - (i == k ? 1.0 : 0.0)), fabs(G[e].y)));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dev = fmax(dev, __shfl_xor(dev, o, 64));
+        if ((t & 63) == 0) deviation[t >> 6] = dev;
+    }
     __syncthreads();
+    if (settled && t == 0)
+        *settled = fmax(fmax(deviation[0], deviation[1]), fmax(deviation[2], deviation[3])) < 1e-7;
     for (int j = 0; j < l; ++j) {
         __syncthreads();
         const double pivot = G[j * l + j].x + shift;
@@ -380,7 +401,8 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
 // row: q_j = (y_j - sum_{i<j} q_i R[i][j]) / R[j][j], q_j = 0 for absent directions (R[j][j] == 0).  One thread per row,
 // 64 rows per workgroup staged through LDS (coalesced both ways); R is wave-uniform, i.e. scalar loads.
 __global__ __launch_bounds__(PANEL_ROWS) void k_panel_solve(amp_t *__restrict__ Y, uint64_t n, int l,
-                                                           const amp_t *__restrict__ R) {
+                                                           const amp_t *__restrict__ R, const int *__restrict__ skip) {
+    if (skip && *skip) return;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     amp_t *tile = reinterpret_cast<amp_t *>(smem_raw);   // [l][PANEL_PITCH]
     amp_t *Rs = tile + l * PANEL_PITCH;                  // [l][l], column-major copy: Rs[j * l + i] = R[i][j]
@@ -954,7 +976,7 @@ bool skinny_gemm(hipStream_t stream, bool transpose, bool conjugate, const amp_t
 // Shifted CholeskyQR3 of the column-major (n x l) panel Y, in place.  `r_total` (l x l, row-major, may be null) receives
 // the triangular factor with  Y_in = Y_out * r_total.
 int panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t *partials, amp_t *r_factor,
-                         amp_t *r_total) {
+                         amp_t *r_total, int *flags = nullptr) {
     const size_t lds = sizeof(amp_t) * l * PANEL_PITCH;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
@@ -972,11 +994,14 @@ int panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t 
     const int gram_blocks = static_cast<int>(tiles < GRAM_BLOCKS ? tiles : GRAM_BLOCKS);
     const unsigned apply_blocks = static_cast<unsigned>(tiles < 4096 ? tiles : 4096);
     for (int round = 0; round < 3; ++round) {
-        hipLaunchKernelGGL(k_panel_gram, dim3(gram_blocks), dim3(256), lds, stream, Y, n, l, partials);
+        // flags[round] tells this round's kernels to return at once; the factor kernel of a round writes flags[round + 1]
+        const int *skip = flags && round > 0 ? flags + round : nullptr;
+        int *next = flags && round < 2 ? flags + round + 1 : nullptr;
+        hipLaunchKernelGGL(k_panel_gram, dim3(gram_blocks), dim3(256), lds, stream, Y, n, l, partials, skip);
         hipLaunchKernelGGL(k_panel_factor, dim3(1), dim3(256), 0, stream, partials, gram_blocks, l, n, round == 0,
-                           round == 0 ? nullptr : r_total, r_total, r_factor);
+                           round == 0 ? nullptr : r_total, r_total, r_factor, skip, next);
         hipLaunchKernelGGL(k_panel_solve, dim3(apply_blocks), dim3(PANEL_ROWS), lds + sizeof(amp_t) * l * l, stream, Y, n, l,
-                           r_factor);
+                           r_factor, skip);
     }
     QSV_HIP(hipGetLastError());
     return QSV_OK;
@@ -1085,9 +1110,8 @@ __global__ __launch_bounds__(256) void k_place_block(amp_t *__restrict__ out, in
 // `r_total` (l x l row-major, may be null) receives the block upper triangular factor with Y_in = Y_out * r_total;
 // `scratch` holds 2 * 64 * 64 amplitudes.
 int wide_panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t *partials, amp_t *scratch,
-                              amp_t *r_total) {
-    if (l <= LMAX && !r_total) return panel_orthonormalise(stream, Y, n, l, partials, scratch, nullptr);
-    if (l <= LMAX) return panel_orthonormalise(stream, Y, n, l, partials, scratch, r_total);
+                              amp_t *r_total, int *flags) {
+    if (l <= LMAX) return panel_orthonormalise(stream, Y, n, l, partials, scratch, r_total, flags);
     static bool raised = false;
     if (!raised) {
         const int big = static_cast<int>((2 * LMAX * PANEL_PITCH) * sizeof(amp_t));
@@ -1116,7 +1140,7 @@ int wide_panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, a
             }
         // the block itself; its triangular factor goes on the diagonal of r_total
         amp_t *diag = r_total ? cross : nullptr;       // w x w, row-major, reuses the cross buffer
-        const int rc = panel_orthonormalise(stream, Yj, n, w, partials, block_factor, diag);
+        const int rc = panel_orthonormalise(stream, Yj, n, w, partials, block_factor, diag, flags);
         if (rc) return rc;
         if (r_total) hipLaunchKernelGGL(k_place_block, dim3(4), dim3(256), 0, stream, r_total, l, c0, c0, diag, w, w);
     }
@@ -1171,9 +1195,10 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
     // small: block scratch (2 x 64 x 64) | r_total | U_r | V_r | library scratch, each L x L
     if (!buf.alloc(&Qn, sizeof(amp_t) * n * L) || !buf.alloc(&Qm, sizeof(amp_t) * m * L) ||
         !buf.alloc(&partials, sizeof(amp_t) * GRAM_BLOCKS * block * block) ||
-        !buf.alloc(&small, sizeof(amp_t) * (scratch_amps + 5 * L * L)) || !buf.alloc(&dS, sizeof(double) * (2 * L + 2)))
+        !buf.alloc(&small, sizeof(amp_t) * (scratch_amps + 5 * L * L)) || !buf.alloc(&dS, sizeof(double) * (2 * L + 6)))
         return qsv_fail(QSV_ENOMEM, "device allocation of the randomized-SVD workspace failed");
     amp_t *r_factor = small, *r_total = small + scratch_amps, *Ur = r_total + L * L, *Vr = Ur + L * L, *lib = Vr + L * L;
+    int *flags = reinterpret_cast<int *>(dS + 2 * L + 2);     // round-skipping flags of the panel kernels (4 ints)
     // theta is row-major (rows x cols); read column-major it is M = theta^T (cols x rows, ld cols).  The reference works on
     // the tall orientation A: wide theta -> A = theta^T = M itself; tall theta -> A = theta = M^T, reached through the
     // transposed / conjugated forms of the panel kernels, so no re-ordered copy of theta is ever made.
@@ -1205,16 +1230,16 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
         return skinny_gemm(stream, false, true, M, panel, out, m, n, l);
     };
     bool ok = times_a(omega, Qn);                                                                 // Y = A O
-    int rc = ok ? wide_panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr) : QSV_OK;
+    int rc = ok ? wide_panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr, flags) : QSV_OK;
     for (int it = 0; ok && !rc && it < q; ++it) {
         ok = times_ah(Qn, Qm);                                                                    // Y = A^H Q
-        if (ok) rc = wide_panel_orthonormalise(stream, Qm, m, l, partials, r_factor, nullptr);
+        if (ok) rc = wide_panel_orthonormalise(stream, Qm, m, l, partials, r_factor, nullptr, flags);
         ok = ok && !rc && times_a(Qm, Qn);                                                        // Y = A Q
-        if (ok) rc = wide_panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr);
+        if (ok) rc = wide_panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr, flags);
     }
     // B^H = A^H Q = Qb Rb  (m x l);  Rb = Ur S Vr^H;  A ~ (Q Vr) S (Qb Ur)^H
     ok = ok && !rc && times_ah(Qn, Qm);
-    if (ok) rc = wide_panel_orthonormalise(stream, Qm, m, l, partials, r_factor, r_total);
+    if (ok) rc = wide_panel_orthonormalise(stream, Qm, m, l, partials, r_factor, r_total, flags);
     if (!ok) return qsv_fail(QSV_EHIP, "rocBLAS call failed in the randomized range finder");
     if (rc) return rc;
     if (L <= LMAX) {
@@ -1357,7 +1382,9 @@ int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream
     LowRankCheck check{0.0, max_bond_dim, full, values};
     for (double v : sums) check.frobenius_squared += v;
     if (!(check.frobenius_squared > 0.0)) return QSV_UNDECIDED;
-    return rsvd_split_fused(a, h, device, stream, theta, rows, cols, keep, l, 7, omega, abs_err, rel_err, m1, m2, capacity,
+    // two power iterations: the route is accepted only when the kept values stand 10^3 rho above everything that was
+    // missed, and the error of their subspace after q iterations is of order (missed / kept)^(2q+1)
+    return rsvd_split_fused(a, h, device, stream, theta, rows, cols, keep, l, 2, omega, abs_err, rel_err, m1, m2, capacity,
                             rank_out, nullptr, &check);
 }
 
