@@ -1350,30 +1350,48 @@ int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream
     const uint64_t full = rows < cols ? rows : cols;
     const int l = LMAX, keep = l - 10;          // one 64-column block of probes: everything stays in the fused kernels
     if (full < 4 * static_cast<uint64_t>(l)) return QSV_UNDECIDED;       // small matrices: the library SVD is cheap
-    DeviceBuffers buf;                                                  // omega and the norm partials: not from the pool,
-    amp_t *omega = nullptr;                                             // which rsvd_split_fused carves for itself
-    double *partials = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&omega), sizeof(amp_t) * full * l) != hipSuccess) return QSV_UNDECIDED;
-    buf.extra[buf.n++] = omega;
-    if (hipMalloc(reinterpret_cast<void **>(&partials), sizeof(double) * 256) != hipSuccess) return QSV_UNDECIDED;
-    buf.extra[buf.n++] = partials;
-    static std::vector<double> host;                                     // the probe matrix, rebuilt when the size changes
-    const bool rebuild = host.size() != 2 * full * l;
-    if (rebuild) host.assign(2 * full * l, 0.0);
-    uint64_t state = 0x9e3779b97f4a7c15ull;                              // splitmix64 + Box-Muller: a fixed probe matrix
-    auto next = [&]() {
-        state += 0x9e3779b97f4a7c15ull;
-        uint64_t z = state;
-        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-        return ((z ^ (z >> 31)) >> 11) * (1.0 / 9007199254740992.0);
+    // the probe matrix and the norm partials live outside the pool (which rsvd_split_fused carves for itself) and are kept
+    // per device: the probes depend only on the size, so they are generated and uploaded once
+    struct Probes {
+        amp_t *omega = nullptr;
+        double *partials = nullptr;
+        uint64_t count = 0;
     };
-    for (uint64_t i = 0; rebuild && i < full * l; ++i) {
-        const double u1 = next() + 1e-300, u2 = next();
-        host[2 * i] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
-        host[2 * i + 1] = 0.0;
+    static Probes cache[16];
+    Probes &probes = cache[device];
+    if (!probes.partials && hipMalloc(reinterpret_cast<void **>(&probes.partials), sizeof(double) * 256) != hipSuccess) {
+        probes.partials = nullptr;
+        return QSV_UNDECIDED;
     }
-    QSV_HIP(hipMemcpyAsync(omega, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice, stream));
+    if (probes.count != full * l) {
+        if (probes.omega) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(probes.omega);
+            probes.omega = nullptr;
+            probes.count = 0;
+        }
+        if (hipMalloc(reinterpret_cast<void **>(&probes.omega), sizeof(amp_t) * full * l) != hipSuccess) {
+            probes.omega = nullptr;
+            return QSV_UNDECIDED;
+        }
+        std::vector<double> host(2 * full * l, 0.0);
+        uint64_t state = 0x9e3779b97f4a7c15ull;                          // splitmix64 + Box-Muller: a fixed probe matrix
+        auto next = [&]() {
+            state += 0x9e3779b97f4a7c15ull;
+            uint64_t z = state;
+            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+            z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+            return ((z ^ (z >> 31)) >> 11) * (1.0 / 9007199254740992.0);
+        };
+        for (uint64_t i = 0; i < full * l; ++i) {
+            const double u1 = next() + 1e-300, u2 = next();
+            host[2 * i] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        }
+        QSV_HIP(hipMemcpy(probes.omega, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
+        probes.count = full * l;
+    }
+    amp_t *omega = probes.omega;
+    double *partials = probes.partials;
     hipLaunchKernelGGL(k_sum_squares, dim3(256), dim3(256), 0, stream, theta, rows * cols, partials);
     QSV_HIP(hipGetLastError());
     double sums[256];
