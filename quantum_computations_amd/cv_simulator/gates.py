@@ -259,7 +259,7 @@ class Mp(Mq):
     """Homodyne measurement of p: inverse Fourier gate, then ``Mq``."""
 
     def apply(self, mps: MPS, **kwargs):
-        mps.reg.apply_mode(fourier_matrix(mps.domain, inv=True), self.index)
+        mps.reg.apply_mode(_cached(self, "inverse fourier", mps.domain, lambda: fourier_matrix(mps.domain, inv=True)), self.index)
         return Mq.apply(self, mps, **kwargs)
 
 
@@ -280,7 +280,7 @@ class Homodyne(Mq):
             outcome = Mq.apply(self, mps, **kwargs)
             outcome.result *= np.round(np.cos(self.arg))
             return outcome
-        mps.reg.apply_mode(rotation_matrix(mps.domain, -self.arg), self.index)
+        mps.reg.apply_mode(_cached(self, "rotation", mps.domain, lambda: rotation_matrix(mps.domain, -self.arg)), self.index)
         return Mq.apply(self, mps, **kwargs)
 
 

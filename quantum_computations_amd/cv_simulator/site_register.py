@@ -37,11 +37,18 @@ from .. import _lib
 OP_NONE, OP_TRANSPOSE, OP_CONJ_TRANSPOSE = 0, 1, 2
 
 
+_TORCH = None
+
+
 def _torch():
-    import torch
-    if not torch.cuda.is_available():
-        raise RuntimeError("SiteRegister needs a HIP device: there is no CPU fallback")
-    return torch
+    """The torch module, after checking once that a HIP device is there (buffers only: allocation, copies, streams)."""
+    global _TORCH
+    if _TORCH is None:
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("SiteRegister needs a HIP device: there is no CPU fallback")
+        _TORCH = torch
+    return _TORCH
 
 
 class SiteRegister:
