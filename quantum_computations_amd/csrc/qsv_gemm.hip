@@ -345,29 +345,78 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
     __syncthreads();
     if (settled && t == 0)
         *settled = fmax(fmax(deviation[0], deviation[1]), fmax(deviation[2], deviation[3])) < 1e-7;
-    for (int j = 0; j < l; ++j) {
+    // Blocked right-looking Cholesky, G = R^H R with R upper, 8 columns per step: the 8 x 8 diagonal block is factored by
+    // the first wave alone (a wavefront executes its LDS instructions in order: no workgroup barriers inside), then all
+    // threads solve the block row and update the trailing matrix -- 3 barriers per 8 columns instead of 3 per column.
+    constexpr int NB = 8;
+    for (int jb = 0; jb < l; jb += NB) {
+        const int nb = l - jb < NB ? l - jb : NB;
         __syncthreads();
-        const double pivot = G[j * l + j].x + shift;
-        const bool gone = !(pivot > pivot_floor);
-        const double rjj = gone ? 1.0 : sqrt(pivot);
-        __syncthreads();
-        if (t == 0) {
-            G[j * l + j] = amp_t{rjj, 0.0};
-            absent[j] = gone;
+        if (t < 64) {
+            for (int p = 0; p < nb; ++p) {
+                const int j = jb + p;
+                const double pivot = G[j * l + j].x + shift;
+                const bool gone = !(pivot > pivot_floor);
+                const double rjj = gone ? 1.0 : sqrt(pivot);
+                __builtin_amdgcn_wave_barrier();
+                if (t == 0) {
+                    G[j * l + j] = amp_t{rjj, 0.0};
+                    absent[j] = gone;
+                }
+                if (t > p && t < nb) {      // the rest of row j inside the diagonal block
+                    const amp_t v = G[j * l + jb + t];
+                    G[j * l + jb + t] = gone ? amp_t{0.0, 0.0} : amp_t{v.x / rjj, v.y / rjj};
+                }
+                __builtin_amdgcn_wave_barrier();
+                {                           // update of the block's remaining entries (i, k), p < i <= k < nb
+                    const int i = t / NB, k = t % NB;
+                    if (i > p && k >= i && k < nb && i < nb) {
+                        const amp_t pr = conj_mul(G[j * l + jb + i], G[j * l + jb + k]);
+                        G[(jb + i) * l + jb + k].x -= pr.x;
+                        G[(jb + i) * l + jb + k].y -= pr.y;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
-        for (int k = j + 1 + t; k < l; k += 256) {
-            const amp_t v = G[j * l + k];
-            G[j * l + k] = gone ? amp_t{0.0, 0.0} : amp_t{v.x / rjj, v.y / rjj};
+        __syncthreads();
+        // block row: R[jb + p][k] for k beyond the block, by forward substitution with the block's R^H
+        for (int k = jb + nb + t; k < l; k += 256) {
+            amp_t x[NB];
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                if (p < nb) {
+                    amp_t acc = G[(jb + p) * l + k];
+#pragma unroll
+                    for (int q = 0; q < NB; ++q)
+                        if (q < p) {
+                            const amp_t pr = conj_mul(G[(jb + q) * l + jb + p], x[q]);
+                            acc.x -= pr.x;
+                            acc.y -= pr.y;
+                        }
+                    const double d = G[(jb + p) * l + jb + p].x;
+                    x[p] = absent[jb + p] ? amp_t{0.0, 0.0} : amp_t{acc.x / d, acc.y / d};
+                    G[(jb + p) * l + k] = x[p];
+                } else {
+                    x[p] = amp_t{0.0, 0.0};
+                }
+            }
         }
         __syncthreads();
-        // trailing update G[i][k] -= conj(R[j][i]) * R[j][k] for j < i <= k
-        const int width = l - j - 1;
+        // trailing update G[i][k] -= sum_p conj(R[jb + p][i]) * R[jb + p][k] for jb + nb <= i <= k
+        const int first = jb + nb, width = l - first;
         for (int e = t; e < width * width; e += 256) {
-            const int i = j + 1 + e / width, k = j + 1 + e % width;
+            const int i = first + e / width, k = first + e % width;
             if (k >= i) {
-                const amp_t p = conj_mul(G[j * l + i], G[j * l + k]);
-                G[i * l + k].x -= p.x;
-                G[i * l + k].y -= p.y;
+                amp_t acc = G[i * l + k];
+#pragma unroll
+                for (int p = 0; p < NB; ++p)
+                    if (p < nb) {
+                        const amp_t pr = conj_mul(G[(jb + p) * l + i], G[(jb + p) * l + k]);
+                        acc.x -= pr.x;
+                        acc.y -= pr.y;
+                    }
+                G[i * l + k] = acc;
             }
         }
     }
