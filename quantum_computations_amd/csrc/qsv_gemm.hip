@@ -446,44 +446,79 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
         for (int e = t; e < entries; e += 256) r_total[e] = Stage[e];
 }
 
-// Y <- Y R^-1 in place for the upper triangular R of k_panel_factor (row-major [i * l + j]), as a forward substitution per
-// row: q_j = (y_j - sum_{i<j} q_i R[i][j]) / R[j][j], q_j = 0 for absent directions (R[j][j] == 0).  One thread per row,
-// 64 rows per workgroup staged through LDS (coalesced both ways); R is wave-uniform, i.e. scalar loads.
-__global__ __launch_bounds__(PANEL_ROWS) void k_panel_solve(amp_t *__restrict__ Y, uint64_t n, int l,
-                                                           const amp_t *__restrict__ R, const int *__restrict__ skip) {
+// Y <- Y R^-1 in place for the upper triangular R of k_panel_factor (row-major [i * l + j]): forward substitution per row,
+// q_j = (y_j - sum_{i<j} q_i R[i][j]) / R[j][j], q_j = 0 for absent directions (R[j][j] == 0), in blocks of 8 columns.
+// A workgroup stages 64 rows through LDS (coalesced both ways) together with a transposed copy of R; for every block the
+// contribution of the columns solved so far is subtracted by all four waves (wave w takes two of the block's columns, so
+// R[i][j] is an LDS broadcast), then the first wave finishes the 8 x 8 triangle for its 64 rows.
+__global__ __launch_bounds__(256) void k_panel_solve(amp_t *__restrict__ Y, uint64_t n, int l,
+                                                    const amp_t *__restrict__ R, const int *__restrict__ skip) {
     if (skip && *skip) return;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     amp_t *tile = reinterpret_cast<amp_t *>(smem_raw);   // [l][PANEL_PITCH]
     amp_t *Rs = tile + l * PANEL_PITCH;                  // [l][l], column-major copy: Rs[j * l + i] = R[i][j]
-    const int r = threadIdx.x;
-    for (int e = r; e < l * l; e += PANEL_ROWS) Rs[(e % l) * l + e / l] = R[e];
+    constexpr int NB = 8;
+    const int t = threadIdx.x, r = t & 63, wave = t >> 6;
+    for (int e = t; e < l * l; e += 256) Rs[(e % l) * l + e / l] = R[e];
     for (uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * PANEL_ROWS; r0 < n;
          r0 += static_cast<uint64_t>(gridDim.x) * PANEL_ROWS) {
         const bool inside = r0 + r < n;
         __syncthreads();
-        for (int c = 0; c < l; ++c)
+        for (int c = wave; c < l; c += 4)
             tile[c * PANEL_PITCH + r] = inside ? Y[static_cast<uint64_t>(c) * n + r0 + r] : amp_t{0.0, 0.0};
-        for (int j = 0; j < l; ++j) {
-            const amp_t *col = Rs + j * l;               // R[0..j][j], read by every lane at once (LDS broadcast)
-            amp_t acc = tile[j * PANEL_PITCH + r];
-            int i = 0;
-            for (; i + 4 <= j; i += 4) {                 // four independent products per step hide the LDS latency
-                const amp_t p0 = plain_mul(tile[(i + 0) * PANEL_PITCH + r], col[i + 0]);
-                const amp_t p1 = plain_mul(tile[(i + 1) * PANEL_PITCH + r], col[i + 1]);
-                const amp_t p2 = plain_mul(tile[(i + 2) * PANEL_PITCH + r], col[i + 2]);
-                const amp_t p3 = plain_mul(tile[(i + 3) * PANEL_PITCH + r], col[i + 3]);
-                acc.x -= (p0.x + p1.x) + (p2.x + p3.x);
-                acc.y -= (p0.y + p1.y) + (p2.y + p3.y);
+        for (int jb = 0; jb < l; jb += NB) {
+            const int nb = l - jb < NB ? l - jb : NB;
+            __syncthreads();
+            // subtract what the solved columns 0 .. jb-1 contribute to this block: wave w owns columns jb + 2w, jb + 2w + 1
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int p = 2 * wave + h;
+                if (p < nb && jb > 0) {
+                    const int j = jb + p;
+                    const amp_t *col = Rs + j * l;
+                    amp_t acc = tile[j * PANEL_PITCH + r];
+                    int i = 0;
+                    for (; i + 4 <= jb; i += 4) {
+                        const amp_t p0 = plain_mul(tile[(i + 0) * PANEL_PITCH + r], col[i + 0]);
+                        const amp_t p1 = plain_mul(tile[(i + 1) * PANEL_PITCH + r], col[i + 1]);
+                        const amp_t p2 = plain_mul(tile[(i + 2) * PANEL_PITCH + r], col[i + 2]);
+                        const amp_t p3 = plain_mul(tile[(i + 3) * PANEL_PITCH + r], col[i + 3]);
+                        acc.x -= (p0.x + p1.x) + (p2.x + p3.x);
+                        acc.y -= (p0.y + p1.y) + (p2.y + p3.y);
+                    }
+                    for (; i < jb; ++i) {
+                        const amp_t pr = plain_mul(tile[i * PANEL_PITCH + r], col[i]);
+                        acc.x -= pr.x;
+                        acc.y -= pr.y;
+                    }
+                    tile[j * PANEL_PITCH + r] = acc;
+                }
             }
-            for (; i < j; ++i) {
-                const amp_t p = plain_mul(tile[i * PANEL_PITCH + r], col[i]);
-                acc.x -= p.x;
-                acc.y -= p.y;
+            __syncthreads();
+            if (wave == 0) {            // the block's own triangle, row by row of the tile: 28 products per row
+                amp_t q[NB];
+#pragma unroll
+                for (int p = 0; p < NB; ++p) {
+                    if (p < nb) {
+                        const int j = jb + p;
+                        const amp_t *col = Rs + j * l;
+                        amp_t acc = tile[j * PANEL_PITCH + r];
+#pragma unroll
+                        for (int u = 0; u < NB; ++u)
+                            if (u < p) {
+                                const amp_t pr = plain_mul(q[u], col[jb + u]);
+                                acc.x -= pr.x;
+                                acc.y -= pr.y;
+                            }
+                        const double d = col[j].x;
+                        q[p] = d != 0.0 ? amp_t{acc.x / d, acc.y / d} : amp_t{0.0, 0.0};
+                        tile[j * PANEL_PITCH + r] = q[p];
+                        if (inside) Y[static_cast<uint64_t>(j) * n + r0 + r] = q[p];
+                    } else {
+                        q[p] = amp_t{0.0, 0.0};
+                    }
+                }
             }
-            const double d = col[j].x;
-            const amp_t q = d != 0.0 ? amp_t{acc.x / d, acc.y / d} : amp_t{0.0, 0.0};
-            tile[j * PANEL_PITCH + r] = q;       // only this thread reads or writes row r of the tile
-            if (inside) Y[static_cast<uint64_t>(j) * n + r0 + r] = q;
         }
     }
 }
@@ -1049,7 +1084,7 @@ int panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t 
         hipLaunchKernelGGL(k_panel_gram, dim3(gram_blocks), dim3(256), lds, stream, Y, n, l, partials, skip);
         hipLaunchKernelGGL(k_panel_factor, dim3(1), dim3(256), 0, stream, partials, gram_blocks, l, n, round == 0,
                            round == 0 ? nullptr : r_total, r_total, r_factor, skip, next);
-        hipLaunchKernelGGL(k_panel_solve, dim3(apply_blocks), dim3(PANEL_ROWS), lds + sizeof(amp_t) * l * l, stream, Y, n, l,
+        hipLaunchKernelGGL(k_panel_solve, dim3(apply_blocks), dim3(256), lds + sizeof(amp_t) * l * l, stream, Y, n, l,
                            r_factor, skip);
     }
     QSV_HIP(hipGetLastError());
