@@ -394,7 +394,11 @@ __global__ __launch_bounds__(256) void k_small_svd(const amp_t *__restrict__ R, 
     const int t = threadIdx.x;
     for (int e = t; e < l * l; e += 256) {
         const int c = e / l, r = e % l;
-        W[c * l + r] = R[r * l + c];
+        // the working matrix is R^H: its columns are the conjugated rows of the upper triangle, which the one-sided sweeps
+        // orthogonalise in fewer passes than the columns of R itself (the triangle's rows are already nearly graded);
+        // R^H = V S U^H, so the caller receives the factors with their roles exchanged
+        const amp_t v = R[c * l + r];
+        W[c * l + r] = amp_t{v.x, -v.y};
         Vw[c * l + r] = amp_t{r == c ? 1.0 : 0.0, 0.0};
     }
     const int lp = (l + 1) & ~1, pairs = lp / 2;
@@ -1161,7 +1165,7 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
     if (!ok) return qsv_fail(QSV_EHIP, "rocBLAS call failed in the randomized range finder");
     if (rc) return rc;
     if (L <= LMAX) {
-        hipLaunchKernelGGL(k_small_svd, dim3(1), dim3(256), 0, stream, r_total, l, Ur, dS, Vr);
+        hipLaunchKernelGGL(k_small_svd, dim3(1), dim3(256), 0, stream, r_total, l, Vr, dS, Ur);   // decomposes R^H: roles swap
         QSV_HIP(hipGetLastError());
     } else {
         // wider than the one-workgroup Jacobi kernel: the library decomposes the l x l factor.  r_total is row-major, i.e.
