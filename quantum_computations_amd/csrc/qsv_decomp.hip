@@ -537,7 +537,8 @@ constexpr int QSV_UNDECIDED = 2;
 bool fused_panels_enabled();
 int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream_t stream, const amp_t *theta,
                           uint64_t rows, uint64_t cols, int64_t max_bond_dim, double abs_err, double rel_err, amp_t *m1,
-                          amp_t *m2, uint64_t capacity, uint64_t *rank_out, std::vector<double> *values);
+                          amp_t *m2, uint64_t capacity, uint64_t *rank_out, std::vector<double> *values,
+                          double *frobenius_squared_out = nullptr);
 
 // tensor_svd (cv_simulator/mps.py:52-97) of a row-major (rows x cols) device matrix:
 //   theta = U S Vh,  r from the truncation rule,  m1 = U[:, :r] sqrt(S[:r]),  m2 = sqrt(S[:r]) Vh[:r, :].
@@ -559,10 +560,11 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
         const char *v = std::getenv("QSV_SVD");
         return !(v && std::string(v) == "exact");
     }();
+    double frobenius_squared = -1.0;      // filled in by the verified route when it gets far enough to measure it
     if (shortcuts_enabled && fused_panels_enabled() && (rel_err >= 1e-4 || abs_err > 0.0)) {
         std::vector<double> values;
         const int fast = try_verified_low_rank(a, h, device, stream, theta, rows, cols, max_bond_dim, abs_err, rel_err, m1, m2,
-                                               capacity, rank_out, s_host ? &values : nullptr);
+                                               capacity, rank_out, s_host ? &values : nullptr, &frobenius_squared);
         if (fast == QSV_OK) {
             if (s_host)
                 for (uint64_t i = 0; i < k; ++i) s_host[i] = values[i];
@@ -599,7 +601,12 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
         const char *v = std::getenv("QSV_SVD");
         return !(v && std::string(v) == "exact");
     }();
-    if (a.zgesdd && gram_route_enabled && (rel_err >= 1e-6 || abs_err > 0.0)) {
+    bool hopeless = false;                // an absolute tolerance far below the scale of theta: zgesdd cannot pass its test
+    if (frobenius_squared > 0.0) {
+        const double norm = sqrt(frobenius_squared);
+        hopeless = (abs_err > rel_err * norm ? abs_err : rel_err * norm) < 1e-5 * norm;
+    }
+    if (a.zgesdd && gram_route_enabled && !hopeless && (rel_err >= 1e-6 || abs_err > 0.0)) {
         amp_t *backup = nullptr;
         if (buf.alloc(&backup, sizeof(amp_t) * rows * cols)) {
             QSV_HIP(hipMemcpyAsync(backup, theta, sizeof(amp_t) * rows * cols, hipMemcpyDeviceToDevice, stream));
@@ -1268,7 +1275,8 @@ __global__ __launch_bounds__(256) void k_sum_squares(const amp_t *__restrict__ x
 // random numbers, so the caller's generator must not be touched -- verified a posteriori by LowRankCheck.
 int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream_t stream, const amp_t *theta,
                           uint64_t rows, uint64_t cols, int64_t max_bond_dim, double abs_err, double rel_err, amp_t *m1,
-                          amp_t *m2, uint64_t capacity, uint64_t *rank_out, std::vector<double> *values) {
+                          amp_t *m2, uint64_t capacity, uint64_t *rank_out, std::vector<double> *values,
+                          double *frobenius_squared_out) {
     const uint64_t full = rows < cols ? rows : cols;
     const int l = LMAX, keep = l - 10;          // one 64-column block of probes: everything stays in the fused kernels
     if (full < 4 * static_cast<uint64_t>(l)) return QSV_UNDECIDED;       // small matrices: the library SVD is cheap
@@ -1321,7 +1329,12 @@ int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream
     QSV_HIP(hipStreamSynchronize(stream));
     LowRankCheck check{0.0, max_bond_dim, full, values};
     for (double v : sums) check.frobenius_squared += v;
+    if (frobenius_squared_out) *frobenius_squared_out = check.frobenius_squared;
     if (!(check.frobenius_squared > 0.0)) return QSV_UNDECIDED;
+    {   // a tolerance below ~1e-5 ||theta||_F can never clear the resolution of the residual: do not even try
+        const double norm = sqrt(check.frobenius_squared), allowed_at_least = abs_err > rel_err * norm ? abs_err : rel_err * norm;
+        if (allowed_at_least < 1e-5 * norm) return QSV_UNDECIDED;
+    }
     // two power iterations: the route is accepted only when the kept values stand 10^3 rho above everything that was
     // missed, and the error of their subspace after q iterations is of order (missed / kept)^(2q+1)
     return rsvd_split_fused(a, h, device, stream, theta, rows, cols, keep, l, 2, omega, abs_err, rel_err, m1, m2, capacity,
