@@ -491,6 +491,128 @@ __global__ __launch_bounds__(256) void k_small_svd(const amp_t *__restrict__ R, 
     for (int rank = t; rank < l; rank += 256) S[rank] = sigma[order[rank]];
 }
 
+// ---- the same one-sided Jacobi SVD for factors wider than 64 columns (up to WIDE_FACTOR): the working matrices live in
+// global memory (L2-resident) and every tournament step is one launch with a wave per column pair ------------------------
+constexpr int WIDE_FACTOR = 256;
+
+// W (column-major l x l) = R^H for the row-major upper triangular R; V = identity
+__global__ __launch_bounds__(256) void k_jacobi_init(const amp_t *__restrict__ R, int l, amp_t *__restrict__ W,
+                                                    amp_t *__restrict__ V) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < l * l; e += gridDim.x * 256) {
+        const int c = e / l, r = e % l;
+        const amp_t v = R[c * l + r];
+        W[e] = amp_t{v.x, -v.y};
+        V[e] = amp_t{r == c ? 1.0 : 0.0, 0.0};
+    }
+}
+
+// one step of the round-robin tournament: block b rotates its pair of columns of W (and of V) if they are not orthogonal
+__global__ __launch_bounds__(64) void k_jacobi_step(amp_t *__restrict__ W, amp_t *__restrict__ V, int l, int lp, int step,
+                                                   int *__restrict__ rotated) {
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    int p, q;
+    if (pair == 0) {
+        p = lp - 1;
+        q = step;
+    } else {
+        p = (step + pair) % (lp - 1);
+        q = (step - pair + (lp - 1)) % (lp - 1);
+    }
+    if (p > q) {
+        const int tmp = p;
+        p = q;
+        q = tmp;
+    }
+    if (q >= l) return;       // the padding column of an odd l sits out
+    amp_t *wp = W + static_cast<size_t>(p) * l, *wq = W + static_cast<size_t>(q) * l;
+    double alpha = 0.0, beta = 0.0;
+    amp_t gamma = {0.0, 0.0};
+    for (int r = lane; r < l; r += 64) {
+        const amp_t x = wp[r], y = wq[r];
+        alpha += x.x * x.x + x.y * x.y;
+        beta += y.x * y.x + y.y * y.y;
+        const amp_t g = conj_mul(x, y);
+        gamma.x += g.x;
+        gamma.y += g.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        alpha += __shfl_xor(alpha, o, 64);
+        beta += __shfl_xor(beta, o, 64);
+        gamma.x += __shfl_xor(gamma.x, o, 64);
+        gamma.y += __shfl_xor(gamma.y, o, 64);
+    }
+    const double eps = 2.220446049250313e-16, g2 = gamma.x * gamma.x + gamma.y * gamma.y;
+    if (!(g2 > eps * eps * alpha * beta) || !(g2 > 0.0)) return;
+    const double g = sqrt(g2);
+    const amp_t phase = {gamma.x / g, -gamma.y / g};
+    const double zeta = (beta - alpha) / (2.0 * g);
+    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + tt * tt), sn = c * tt;
+    amp_t *vp = V + static_cast<size_t>(p) * l, *vq = V + static_cast<size_t>(q) * l;
+    for (int r = lane; r < l; r += 64) {
+        const amp_t x = wp[r], y = plain_mul(wq[r], phase);
+        wp[r] = amp_t{c * x.x - sn * y.x, c * x.y - sn * y.y};
+        wq[r] = amp_t{sn * x.x + c * y.x, sn * x.y + c * y.y};
+        const amp_t vx = vp[r], vy = plain_mul(vq[r], phase);
+        vp[r] = amp_t{c * vx.x - sn * vy.x, c * vx.y - sn * vy.y};
+        vq[r] = amp_t{sn * vx.x + c * vy.x, sn * vx.y + c * vy.y};
+    }
+    if (lane == 0) *rotated = 1;
+}
+
+// singular values = column norms of W, sorted decreasingly; left = W / sigma, right = V in that order (column-major)
+__global__ __launch_bounds__(256) void k_jacobi_finish(const amp_t *__restrict__ W, const amp_t *__restrict__ V, int l,
+                                                      amp_t *__restrict__ left, double *__restrict__ S,
+                                                      amp_t *__restrict__ right) {
+    __shared__ double sigma[WIDE_FACTOR];
+    __shared__ int order[WIDE_FACTOR];
+    const int t = threadIdx.x;
+    for (int c = t; c < l; c += 256) {
+        double s = 0.0;
+        for (int r = 0; r < l; ++r) {
+            const amp_t w = W[static_cast<size_t>(c) * l + r];
+            s += w.x * w.x + w.y * w.y;
+        }
+        sigma[c] = sqrt(s);
+    }
+    __syncthreads();
+    for (int c = t; c < l; c += 256) {
+        int rank = 0;
+        for (int o = 0; o < l; ++o) rank += sigma[o] > sigma[c] || (sigma[o] == sigma[c] && o < c);
+        order[rank] = c;
+    }
+    __syncthreads();
+    for (int e = t; e < l * l; e += 256) {
+        const int rank = e / l, r = e % l, c = order[rank];
+        const double s = sigma[c];
+        const amp_t w = W[static_cast<size_t>(c) * l + r];
+        left[e] = s > 0.0 ? amp_t{w.x / s, w.y / s} : amp_t{0.0, 0.0};
+        right[e] = V[static_cast<size_t>(c) * l + r];
+    }
+    for (int rank = t; rank < l; rank += 256) S[rank] = sigma[order[rank]];
+}
+
+// R = U_r S V_r^H for the row-major l x l triangle R, 64 < l <= WIDE_FACTOR.  W, V: 2 l^2 amplitudes of scratch; `flag`
+// one device int.  (The kernels decompose R^H = V_r S U_r^H, hence the exchanged output arguments.)
+int wide_factor_svd(hipStream_t stream, const amp_t *R, int l, amp_t *W, amp_t *V, amp_t *Ur, double *S, amp_t *Vr,
+                    int *flag) {
+    hipLaunchKernelGGL(k_jacobi_init, dim3(64), dim3(256), 0, stream, R, l, W, V);
+    const int lp = (l + 1) & ~1;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        QSV_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream));
+        for (int step = 0; step < lp - 1; ++step)
+            hipLaunchKernelGGL(k_jacobi_step, dim3(lp / 2), dim3(64), 0, stream, W, V, l, lp, step, flag);
+        int rotated = 0;
+        QSV_HIP(hipMemcpyAsync(&rotated, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+        QSV_HIP(hipStreamSynchronize(stream));
+        if (!rotated) break;
+    }
+    hipLaunchKernelGGL(k_jacobi_finish, dim3(1), dim3(256), 0, stream, W, V, l, Vr, S, Ur);
+    QSV_HIP(hipGetLastError());
+    return QSV_OK;
+}
+
 // out[a, b] (row-major A x B) = sqrt(s[by_row ? a : b]) * (conj ? conj(in[...]) : in[a * sa + b * sb])
 __global__ __launch_bounds__(QSV_BLOCK) void k_scale_strided_conj(const amp_t *__restrict__ in, amp_t *__restrict__ out,
                                                                  uint64_t A, uint64_t B, uint64_t sa, uint64_t sb,
@@ -1175,28 +1297,15 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
         hipLaunchKernelGGL(k_small_svd, dim3(1), dim3(256), 0, stream, r_total, l, Vr, dS, Ur);   // decomposes R^H: roles swap
         QSV_HIP(hipGetLastError());
     } else {
-        // wider than the one-workgroup Jacobi kernel: the library decomposes the l x l factor.  r_total is row-major, i.e.
-        // X = R^T column-major; X = U' S V'^H gives R = conj(V') S U'^T, so U_r = (V'^H)^T and V_r = conj(U').
-        if (!a.zgesvd) return qsv_fail(QSV_EHIP, "rocSOLVER could not be loaded (librocsolver.so.0): no SVD available");
-        amp_t *Uprime = lib, *Vh = lib + L * L;     // lib has 2 L^2: U' and V'^H
-        double *dE = dS + L;
-        rocblas_int *dinfo = reinterpret_cast<rocblas_int *>(dS + 2 * L);
-        if (a.zgesvd(h, rocblas_svect_singular, rocblas_svect_singular, li, li, W(r_total), li, dS, W(Uprime), li, W(Vh), li, dE,
-                     rocblas_outofplace, dinfo) != rocblas_status_success)
-            return qsv_fail(QSV_EHIP, "rocsolver_zgesvd failed");
-        hipLaunchKernelGGL(k_small_reorder, dim3(16), dim3(256), 0, stream, Vh, Ur, l, 0);
-        hipLaunchKernelGGL(k_small_reorder, dim3(16), dim3(256), 0, stream, Uprime, Vr, l, 1);
-        QSV_HIP(hipGetLastError());
+        // wider than the one-workgroup Jacobi kernel: the same sweeps with the working matrices in global memory, one
+        // launch per tournament step (rocSOLVER's zgesvd spends ~25 ms in bdsqr launch storms on a 110 x 110 factor)
+        const int rc_svd = wide_factor_svd(stream, r_total, l, lib, lib + L * L, Ur, dS, Vr, flags + 3);
+        if (rc_svd) return rc_svd;
     }
     const uint64_t k = verify ? L : static_cast<uint64_t>(k_keep);
     std::vector<double> sv(k);
-    rocblas_int svd_info = 0;
     QSV_HIP(hipMemcpyAsync(sv.data(), dS, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
-    if (L > LMAX)
-        QSV_HIP(hipMemcpyAsync(&svd_info, reinterpret_cast<rocblas_int *>(dS + 2 * L), sizeof(svd_info), hipMemcpyDeviceToHost,
-                               stream));
     QSV_HIP(hipStreamSynchronize(stream));
-    if (svd_info != 0) return qsv_fail(QSV_EHIP, "rocsolver_zgesvd did not converge on the projected factor");
     uint64_t r;
     if (verify) {
         // What the projection misses: rho^2 = ||A||_F^2 - sum sigma~_i^2 = ||(I - Q Q^H) A||_F^2 exactly, so every true
