@@ -1308,31 +1308,34 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
     QSV_HIP(hipStreamSynchronize(stream));
     uint64_t r;
     if (verify) {
-        // What the projection misses: rho^2 = ||A||_F^2 - sum sigma~_i^2 = ||(I - Q Q^H) A||_F^2 exactly, so every true
-        // singular value differs from its computed counterpart by at most rho, and the uncaptured ones sum to at most
-        // sqrt(full - l) rho.  rho itself is resolved down to ~1e-8 ||A|| (it is a difference of squares).
+        // What the projection misses: rho^2 = ||A||_F^2 - sum sigma~_i^2 = ||(I - Q Q^H) A||_F^2 exactly.  With
+        // d_i = sigma_i^2 - sigma~_i^2 >= 0 (i <= l; singular values of a compression never exceed the true ones) and
+        // d_i = sigma_i^2 (i > l) one has sum d_i = rho^2 and sigma_i - sigma~_i <= sqrt(d_i), so every true tail sum lies
+        // in [T~_j, T~_j + sqrt(full) rho] (Cauchy-Schwarz).  rho itself is resolved down to ~1e-8 ||A||.
         double captured = 0.0;
         for (double v : sv) captured += v * v;
         const double f2 = verify->frobenius_squared;
         double rho2 = f2 - captured;
         const double resolution = 4e-16 * static_cast<double>(L) * f2;
         if (rho2 < resolution) rho2 = resolution;
-        const double rho = sqrt(rho2), missing = sqrt(static_cast<double>(verify->full_rank - L)) * rho;
-        const double margin = (static_cast<double>(L) * rho + missing) * (1.0 + rel_err);
+        const double rho = sqrt(rho2), margin = sqrt(static_cast<double>(verify->full_rank)) * rho;
         const double allowed = allowed_error(sv, abs_err, rel_err);
         static const bool trace = std::getenv("QSV_TRACE_SPLIT") != nullptr;
         if (trace)
             fprintf(stderr, "[qsv split] %llu x %llu: probes %d, ||A||_F %.3e, rho %.3e, allowed %.3e, margin %.3e, s0 %.3e\n",
                     static_cast<unsigned long long>(rows), static_cast<unsigned long long>(cols), l, sqrt(f2), rho, allowed,
                     margin, sv[0]);
-        if (!(allowed > 2.0 * margin)) return QSV_UNDECIDED;
-        const uint64_t r_lo = kept_rank_for(sv, verify->max_bond_dim, allowed + margin);
+        if (!(allowed > margin)) return QSV_UNDECIDED;
+        // true tail sums are the computed ones plus something in [0, margin]; the true allowance is the computed one plus
+        // at most rel_err * margin: the rank is settled if no computed tail sum falls between these two thresholds
+        const uint64_t r_lo = kept_rank_for(sv, verify->max_bond_dim, allowed + rel_err * margin);
         const uint64_t r_hi = kept_rank_for(sv, verify->max_bond_dim, allowed - margin);
         if (trace)
             fprintf(stderr, "[qsv split]   r in [%llu, %llu], s[r-1] %.3e\n", static_cast<unsigned long long>(r_lo),
                     static_cast<unsigned long long>(r_hi), r_lo > 0 ? sv[r_lo - 1] : 0.0);
-        // the kept triplets must sit well inside the captured block and far above what was missed
-        if (r_lo != r_hi || r_lo > static_cast<uint64_t>(k_keep) || (r_lo > 0 && !(sv[r_lo - 1] > 1e3 * rho)))
+        // the kept triplets must sit well inside the captured block and far above what was missed (their subspace error
+        // after q power iterations is of order (rho / sigma_r)^(2q+1))
+        if (r_lo != r_hi || r_lo > static_cast<uint64_t>(k_keep) || (r_lo > 0 && !(sv[r_lo - 1] > 1e2 * rho)))
             return QSV_UNDECIDED;
         r = r_lo;
         if (verify->values) {
