@@ -189,6 +189,15 @@ def main():
     with np.testing.assert_raises(ValueError):
         st.insert(st.num_qubits + 1, [1, 0])
 
+    # 3a'. fused circuits (Simulator(fuse=k)): dense blocks of up to k qubits with local and remote legs
+    ops = W.random_circuit(n, 90, 43)
+    ket = W.random_ket(n, 7)
+    want, _ = O.run_circuit(ops, ket)
+    for k in (3, 5):
+        st = make_state(n, ket, args.backend, device)
+        out = Simulator(W.to_gates(ops), fuse=k).run(st)
+        check(f"fused circuit, blocks of <= {k} qubits", out.to_numpy(), want)
+
     # 3b. BASELINE config 5 in small: Grover search on the sharded register, success probability vs the analytic value
     marked = (0b1011001110 >> max(0, 10 - n)) | 1
     start = np.zeros(1 << n, dtype=complex)
