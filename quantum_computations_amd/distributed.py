@@ -8,9 +8,17 @@ the reference is big-endian -- SURVEY.md 8e).  A gate is then one of:
 * **block-diagonal in a remote leg** (diagonal gates, controls: Z, RZ, T, CZ, the control of CX, ...): the rank's
   own bit value selects the sub-block to apply locally -- still no traffic;
 * **mixing a remote leg** (H, X, a Haar gate, the target of CX on a remote qubit): that qubit is first made
-  local by swapping its physical bit with the top local bit -- a pairwise exchange of half a shard with rank
-  ``r ^ bit`` (``batch_isend_irecv`` -> ncclSend/ncclRecv grouped) -- after which the gate is local.  The swap is
-  *not* undone: the register keeps a logical -> physical bit map, so later gates on that qubit stay local.
+  local by an exchange step (grouped ``ncclSend``/``ncclRecv`` through ``batch_isend_irecv``), after which the gate
+  is local.  With two ranks that is the pairwise swap of half a shard with rank ``r ^ 1``.  With four or more ranks
+  ALL g rank bits are swapped with g local bits in one all-to-all: every rank keeps 1/G of its shard and sends 1/G
+  to each of the other G - 1 ranks, so all of a GPU's xGMI links carry shard/G at the same time -- the time of ONE
+  pairwise half-shard swap routed over all links, for g qubits instead of one (mitigation 1).  The
+  qubits that leave are the local qubits whose next mixing use lies farthest ahead (``prepare``).  Swaps are *not*
+  undone: the register keeps a logical -> physical bit map, so later gates on those qubits stay local.
+
+Every exchange moves the data in pieces of at most ``chunk_amps`` amplitudes (1 GiB) through a two-piece staging
+buffer: while piece c is on the links, piece c-1 is copied into place, so the staging memory stays at 2 GiB however
+large the shard is (a 34-qubit register has 32 GiB shards).
 
 The class is written against a small "local engine" interface (the methods of ``DeviceState`` it uses) and
 against torch tensors for the exchange, so the sharding logic runs unchanged on CPU tensors with the ``gloo``
@@ -53,38 +61,80 @@ def _restrict_leg(m: np.ndarray, k: int, leg: int, value: int) -> np.ndarray:
     return np.ascontiguousarray(t[tuple(idx)]).reshape(1 << (k - 1), 1 << (k - 1))
 
 
+CHUNK_AMPS = 1 << 26      # staging piece: 2^26 amplitudes = 1 GiB (bounded exchange buffers)
+
+
+class _DryEngine:
+    """Stand-in local engine of a layout-only ``ShardedState`` (``ShardedState.plan_only``): accepts every call and
+    does nothing, so the exchange schedule of a circuit can be computed without a register or a process group."""
+
+    def __getattr__(self, name):
+        def method(*args, **kwargs):
+            if name == "measure_probs":
+                return 0.5, 0.5
+            if name in ("norm2", "fill_random"):
+                return 1.0
+            return self
+        return method
+
+
 class ShardedState:
     """n-qubit complex128 register sharded over ``world`` ranks (a power of two)."""
 
     ndim = 1
 
-    def __init__(self, n_qubits: int, buf, engine_factory, group=None):
-        import torch.distributed as dist
+    def __init__(self, n_qubits: int, buf, engine_factory, group=None, *, chunk_amps: int | None = None,
+                 policy: str = "auto", _dry: tuple[int, int] | None = None):
+        """``policy``: which exchange brings a remote qubit into the shards -- ``"auto"`` (all rank bits at once when
+        there are four or more ranks, the pairwise half-shard swap otherwise), ``"pairwise"`` (always one qubit)."""
+        if _dry is None:
+            import torch.distributed as dist
 
-        self._dist = dist
-        self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+            self._dist = dist
+            self.group = group
+            self.world = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+        else:
+            self._dist, self.group = None, None
+            self.world, self.rank = _dry
         self.g = (self.world - 1).bit_length()
         if 1 << self.g != self.world:
             raise ValueError("the register shards over a power-of-two number of ranks")
         if n_qubits < self.g + 1:
             raise ValueError("need at least one local qubit per rank")
+        if policy not in ("auto", "pairwise"):
+            raise ValueError("policy must be 'auto' or 'pairwise'")
         self.n = n_qubits
         self.n_local = n_qubits - self.g
         self.buf = buf                                    # torch tensor, 2^n_local complex128, this rank's shard
         self._factory = engine_factory
-        self.local = engine_factory(buf, self.n_local)
-        self._scratch = None                              # half-shard receive buffer, allocated on first exchange
+        self.local = _DryEngine() if _dry is not None else engine_factory(buf, self.n_local)
+        self._scratch = None                              # two staging pieces, allocated on first exchange
+        import os
+        self.chunk_amps = int(chunk_amps or os.environ.get("QSV_EXCHANGE_CHUNK_AMPS", CHUNK_AMPS))
+        if self.chunk_amps < 1 or self.chunk_amps & (self.chunk_amps - 1):
+            raise ValueError("chunk_amps must be a power of two")
+        self.policy = policy
         # physical bit position of each logical bit (logical bit b = reference qubit n-1-b)
         self.phys = list(range(n_qubits))
-        self.exchanges = 0                                # half-shard exchanges performed (for reports)
-        self.bytes_sent = 0
+        self.exchanges = 0                                # exchange steps performed (for reports)
+        self.qubits_exchanged = 0                         # rank bits swapped in by those steps
+        self.bytes_sent = 0                               # bytes this rank put on the links
+        self.link_bytes = 0                               # bytes over its busiest link (xGMI is point to point: this
+                                                          # is what an exchange's duration is proportional to)
+        self.messages = 0                                 # point-to-point messages this rank sent
+        self.local_swaps = 0                              # local passes spent lining victims up for an exchange
         self._plan = None                                 # look-ahead set by prepare(): [(indices, mixing qubits)]
         self._cursor = 0
-        self.multipath = True                             # route exchanges over all links (see _exchange)
 
     # ---- construction ---------------------------------------------------------------------------
+    @classmethod
+    def plan_only(cls, n_qubits: int, world: int, policy: str = "auto") -> "ShardedState":
+        """A register without data: gates only update the qubit layout and the exchange counters.  The layout logic
+        never depends on the rank, so this tells what every rank of a ``world``-rank run will do (bench reports,
+        tests of the scheduling policy)."""
+        return cls(n_qubits, None, None, policy=policy, _dry=(world, 0))
+
     @classmethod
     def random(cls, n_qubits: int, seed: int, device: int = 0, group=None) -> "ShardedState":
         """Normalised pseudo-random register generated shard by shard on the GPUs (counter-based)."""
@@ -112,8 +162,6 @@ class ShardedState:
         return st
 
     def fill_random(self, seed: int) -> None:
-        import torch
-
         n2 = self.local.fill_random(seed, index_offset=self.rank << self.n_local, normalise=False)
         self.local.apply_scale(1.0 / float(np.sqrt(self._allreduce_sum([n2])[0])))
         self.phys = list(range(self.n))
@@ -142,6 +190,10 @@ class ShardedState:
     def _local_qubit(self, phys_bit: int) -> int:
         return self.n_local - 1 - phys_bit
 
+    def remote_qubits(self) -> list[int]:
+        """Reference indices of the qubits that currently sit on rank bits."""
+        return sorted(self.n - 1 - lb for lb, p in enumerate(self.phys) if p >= self.n_local)
+
     def sync(self) -> None:
         self.local.sync()
 
@@ -150,50 +202,40 @@ class ShardedState:
         if bit_a == bit_b:
             return
         self.local.apply_swap(self._local_qubit(bit_a), self._local_qubit(bit_b))
+        self.local_swaps += 1
         ia, ib = self.phys.index(bit_a), self.phys.index(bit_b)
         self.phys[ia], self.phys[ib] = bit_b, bit_a
 
     # The three collectives the register needs.  Kept as small methods so that a test can stage them through
     # host memory (gloo on a box with fewer GPUs than ranks); production uses them as written, on RCCL.
-    def _exchange(self, send, recv, peer: int) -> None:
-        """Deliver ``send`` to ``peer`` and receive its ``send`` into ``recv``.  Every rank calls this in the same
-        step with the same rank mask (``peer = rank ^ mask``), which is what makes the multi-path form legal.
-
-        xGMI is point to point: the direct link to ``peer`` is one of seven, so a plain send/recv pair leaves 6/7 of
-        a GPU's links idle.  With 4 or more ranks the half shard is therefore cut into ``world`` chunks that travel
-        over *all* links: chunk y goes to rank y first (one ``all_to_all_single``), every rank hands the chunks it
-        holds for x over to ``x ^ mask`` (a second ``all_to_all_single``), and each directed link carries one chunk
-        per phase -- world/2 times less time than the direct transfer.  ``send`` is overwritten (its content has
-        left the rank by then)."""
+    def _p2p(self, sends, recvs):
+        """Start one grouped point-to-point step: ``sends`` / ``recvs`` are lists of ``(peer rank, tensor)``.
+        Returns an object with ``wait()``.  On RCCL this is one ncclGroupStart/End of ncclSend/ncclRecv on the
+        communicator's own stream; ``wait()`` makes the current stream wait for it (no host block), so the caller's
+        next copy kernel overlaps with whatever group is issued after this one."""
         import torch
 
         dist = self._dist
-        # RCCL has no complex dtype: move the amplitudes as (re, im) float64 pairs (same bytes, no copy)
-        send_r, recv_r = torch.view_as_real(send), torch.view_as_real(recv)
-        if self.multipath and self.world >= 4 and send.numel() % self.world == 0:
-            mask = self.rank ^ peer
-            try:
-                dist.all_to_all_single(recv_r, send_r, group=self.group)    # phase 1: chunk y -> rank y
-            except (RuntimeError, TypeError, ValueError, NotImplementedError) as exc:
-                # a backend that rejects the collective does so while validating its arguments -- before anything is
-                # sent, and identically on every rank -- so all ranks fall back to the direct transfer together
-                import warnings
-                warnings.warn(f"all_to_all_single unavailable ({exc}); using direct send/recv for qubit exchanges")
-                self.multipath = False
-                return self._exchange(send, recv, peer)
-            relay = recv_r.view(self.world, -1)
-            staged = send_r.view(self.world, -1)
-            order = torch.tensor([z ^ mask for z in range(self.world)], device=send.device)
-            torch.index_select(relay, 0, order, out=staged)                 # slot z <- chunk held for z ^ mask
-            dist.all_to_all_single(recv_r, send_r, group=self.group)        # phase 2: hand over to the owners
-            return
-        peer_global = dist.get_global_rank(self.group, peer) if self.group is not None else peer
-        ops = [dist.P2POp(dist.isend, send_r, peer_global, self.group),
-               dist.P2POp(dist.irecv, recv_r, peer_global, self.group)]
-        for work in dist.batch_isend_irecv(ops):
-            work.wait()
+        ops = []
+        for peer, t in sends:
+            p = dist.get_global_rank(self.group, peer) if self.group is not None else peer
+            # RCCL has no complex dtype: move the amplitudes as (re, im) float64 pairs (same bytes, no copy)
+            ops.append(dist.P2POp(dist.isend, torch.view_as_real(t), p, self.group))
+        for peer, t in recvs:
+            p = dist.get_global_rank(self.group, peer) if self.group is not None else peer
+            ops.append(dist.P2POp(dist.irecv, torch.view_as_real(t), p, self.group))
+        works = dist.batch_isend_irecv(ops)
+
+        class _Step:
+            @staticmethod
+            def wait():
+                for w in works:
+                    w.wait()
+        return _Step
 
     def _allreduce_sum(self, values: list[float]) -> list[float]:
+        if self._dist is None:
+            return [float(v) for v in values]
         import torch
 
         t = torch.tensor(values, dtype=torch.float64, device=self.buf.device)
@@ -208,13 +250,68 @@ class ShardedState:
         self._dist.all_gather(shards, mine, group=self.group)
         return torch.view_as_complex(torch.cat(shards)).cpu().numpy()
 
-    # ---- look-ahead: which local qubit to give up ---------------------------------------------------
+    def _exchange_bits(self, gbits: list[int]) -> None:
+        """Swap the rank bits ``gbits`` (ascending physical positions) with the top ``len(gbits)`` local bits.
+
+        The 2^k ranks that differ only in ``gbits`` form a subgroup; the shard is 2^k contiguous pieces (one per
+        value j of its top k local bits).  Piece j goes to the subgroup member whose ``gbits`` spell j, and that
+        member's piece number <my gbits value> comes back into the same slot; the piece with j = my own value stays.
+        k = 1 is the pairwise half-shard swap, k = g the all-to-all over every link.  The pieces travel in slices of
+        at most ``chunk_amps / (2^k - 1)`` amplitudes through two staging slices: slice c is on the links while
+        slice c-1 is copied into place."""
+        k = len(gbits)
+        parts = 1 << k
+        piece = 1 << (self.n_local - k)
+        mine = sum(self._rank_bit(gb) << i for i, gb in enumerate(gbits))
+        mask = sum(1 << (gb - self.n_local) for gb in gbits)
+        peers = [(self.rank & ~mask) | sum(((j >> i) & 1) << (gb - self.n_local) for i, gb in enumerate(gbits))
+                 for j in range(parts)]
+        others = [j for j in range(parts) if j != mine]
+        cs = self.chunk_amps // (parts - 1)
+        cs = 1 << max(0, cs.bit_length() - 1)             # power of two, so it divides the piece
+        cs = min(cs, piece)
+        steps = piece // cs
+        self.exchanges += 1
+        self.qubits_exchanged += k
+        self.bytes_sent += len(others) * piece * 16
+        self.link_bytes += piece * 16
+        self.messages += len(others) * steps
+        if self.buf is not None:
+            import torch
+
+            stage = len(others) * cs
+            if self._scratch is None or self._scratch.numel() < 2 * stage:
+                self._scratch = torch.empty(2 * stage, dtype=self.buf.dtype, device=self.buf.device)
+            self.local.sync()                              # the shard is final before its pieces leave
+
+            def land(step, c, half):
+                step.wait()
+                for slot, j in enumerate(others):
+                    self.buf[j * piece + c * cs:j * piece + (c + 1) * cs].copy_(half[slot * cs:(slot + 1) * cs])
+
+            pending = None
+            for c in range(steps):
+                half = self._scratch[(c & 1) * stage:(c & 1) * stage + stage]
+                sends = [(peers[j], self.buf[j * piece + c * cs:j * piece + (c + 1) * cs]) for j in others]
+                recvs = [(peers[j], half[slot * cs:(slot + 1) * cs]) for slot, j in enumerate(others)]
+                step = self._p2p(sends, recvs)             # slice c is on the links ...
+                if pending is not None:
+                    land(*pending)                         # ... while slice c-1 is copied into place
+                pending = (step, c, half)
+            land(*pending)
+        # the logical bit that lived on top-local slot i now lives on gbits[i], and vice versa
+        for i, gb in enumerate(gbits):
+            slot = self.n_local - k + i
+            i_slot, i_g = self.phys.index(slot), self.phys.index(gb)
+            self.phys[i_slot], self.phys[i_g] = gb, slot
+
+    # ---- look-ahead: which local qubits to give up --------------------------------------------------
     def prepare(self, circuit) -> None:
         """Tell the register which gates are about to be applied (objects with ``indices`` / ``matrix``, in order).
 
-        With the plan, an exchange evicts the local qubit whose next *mixing* use lies farthest ahead (Belady's
-        rule) instead of whichever qubit sits on the top local bit, which cuts the number of half-shard exchanges
-        of a random circuit several-fold.  Purely an optimisation: every rank computes the same plan from the same
+        With the plan, an exchange evicts the local qubits whose next *mixing* use lies farthest ahead (Belady's
+        rule) instead of whichever qubits sit on the top local bits, which cuts the number of exchanges of a random
+        circuit several-fold.  Purely an optimisation: every rank computes the same plan from the same
         circuit, a gate that does not match the plan simply switches the look-ahead off, and the plan stops at the
         first measurement / insertion (they renumber the qubits)."""
         plan = []
@@ -243,42 +340,37 @@ class ShardedState:
                 return step
         return 1 << 60
 
-    def _choose_victim(self, avoid: set[int]) -> int:
-        top = self.n_local - 1
+    def _choose_victims(self, count: int, avoid: set[int]) -> list[int]:
+        """``count`` local bits whose qubits leave the shard, never one of ``avoid``."""
         free = [b for b in range(self.n_local) if b not in avoid]
-        if not free:
+        if len(free) < count:
             raise ValueError("gate has more legs than a shard has qubits")
         if self._plan is None:
-            return top if top in free else max(free)
-        # farthest next use first; among equals the highest bit (the top bit needs no local swap)
-        return max(free, key=lambda b: (self._next_mixing_use(self.n - 1 - self.phys.index(b)), b))
+            return sorted(free)[-count:]                             # the top bits need no local swap
+        # farthest next use first; among equals the highest bit
+        free.sort(key=lambda b: (self._next_mixing_use(self.n - 1 - self.phys.index(b)), b), reverse=True)
+        return free[:count]
 
     def _localise(self, gbit: int, avoid: set[int]) -> int:
-        """Swap global physical bit ``gbit`` with the top local bit (kept clear of ``avoid``); returns the
-        local bit the qubit now occupies.  One half-shard send + receive with rank ``r ^ (1 << (gbit - n_local))``."""
-        import torch
-
-        top = self.n_local - 1
-        victim = self._choose_victim(avoid)     # local bit whose qubit leaves the shard
-        if victim != top:                       # halves are contiguous only for the top bit: bring the victim there
-            self._swap_bits_local(top, victim)  # (one local pass; an exchange costs ~30x more)
-        half = 1 << top
-        mine = self._rank_bit(gbit)
-        peer = self.rank ^ (1 << (gbit - self.n_local))
-        # the (G = mine, L = mine) half stays; the (G = mine, L = 1 - mine) half goes to the peer, whose
-        # (G = 1 - mine, L = mine) half takes its place
-        give = self.buf[(1 - mine) * half:(2 - mine) * half]
-        if self._scratch is None or self._scratch.numel() < half:
-            self._scratch = torch.empty(half, dtype=self.buf.dtype, device=self.buf.device)
-        recv = self._scratch[:half]
-        self._exchange(give, recv, peer)
-        give.copy_(recv)
-        self.exchanges += 1
-        self.bytes_sent += half * 16
-        # the logical bit that lived on `top` now lives on `gbit`, and vice versa
-        i_top, i_g = self.phys.index(top), self.phys.index(gbit)
-        self.phys[i_top], self.phys[i_g] = gbit, top
-        return top
+        """Bring the qubit on rank bit ``gbit`` into the shard (the local bits in ``avoid`` stay); returns the local
+        bit it now occupies.  Every rank takes the same decisions: they depend on the layout and the plan only."""
+        logical = self.phys.index(gbit)
+        free = self.n_local - len(avoid)
+        if self.policy == "auto" and self.g >= 2 and free >= self.g:
+            gbits = list(range(self.n_local, self.n))                # all rank bits in one all-to-all
+        else:
+            gbits = [gbit]                                           # pairwise half-shard swap with rank r ^ bit
+        k = len(gbits)
+        victims = self._choose_victims(k, avoid)
+        # the pieces are contiguous only if the victims sit on the top k local bits: line them up (local passes;
+        # an exchange costs 30x more).  Victims already inside the top block keep their slot.
+        top = list(range(self.n_local - k, self.n_local))
+        outside = [v for v in victims if v not in top]
+        for slot in top:
+            if slot not in victims:
+                self._swap_bits_local(slot, outside.pop())
+        self._exchange_bits(gbits)
+        return self.phys[logical]
 
     # ---- gates ----------------------------------------------------------------------------------
     #
@@ -414,7 +506,6 @@ class ShardedState:
         self.phys.insert(new_logical_bit, 0)
         self.n += 1
         self.n_local += 1
-        self._scratch = None                                   # half-shard buffers have the wrong size now
         self._plan = None
         return self
 
@@ -427,6 +518,16 @@ class ShardedState:
             b = self._localise(b, set())
         p0, p1 = self._allreduce_sum(list(self.local.measure_probs(self._local_qubit(b), eig0, eig1)))
         return p0, p1
+
+    def agree_on_outcome(self, outcome: int) -> int:
+        """The measurement outcome every rank must use: rank 0's draw.
+
+        ``M.apply`` draws from the process-global ``np.random`` like the reference (gates.py:183).  One process per
+        GPU means one generator per rank, and nothing keeps their states equal; shards that collapsed onto different
+        outcomes would be a silently wrong register (and diverging ``Simulator.results`` would send later exchanges
+        to partners that never post them).  Every rank still draws -- ranks seeded alike stay in step with a
+        single-process run of the same script -- but rank 0's bit is the one applied."""
+        return int(round(self._allreduce_sum([float(outcome) if self.rank == 0 else 0.0])[0]))
 
     def collapse(self, index: int, eig, scale: float) -> "ShardedState":
         """Project reference qubit ``index`` on ``eig`` and drop it: every shard shrinks by half."""

@@ -208,6 +208,8 @@ class M(SingleQubitGate):
         eigs = self.eigenvectors()
         probs = dev.measure_probs(self.indices[0], *eigs)
         s = np.random.choice([0, 1], p=list(probs)) if self.result is None else self.result
+        if self.result is None and hasattr(dev, "agree_on_outcome"):
+            s = dev.agree_on_outcome(int(s))      # sharded registers: one generator per rank, one outcome for all
         dev.collapse(self.indices[0], eigs[s], 1.0 / np.sqrt(probs[s]))
         return int(s)
 

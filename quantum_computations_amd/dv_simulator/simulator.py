@@ -68,7 +68,8 @@ class Simulator:
         dev = DeviceState.from_numpy(state, self._device) if on_host else state
         if self._fuse >= 2:
             from ..fusion import fuse_circuit
-            self.launch_list = fuse_circuit(self.circuit, self._fuse, n_qubits=dev.num_qubits)
+            remote = dev.remote_qubits() if hasattr(dev, "remote_qubits") else ()
+            self.launch_list = fuse_circuit(self.circuit, self._fuse, n_qubits=dev.num_qubits, remote=remote)
         else:
             self.launch_list = self.circuit
         if hasattr(dev, "prepare"):

@@ -60,8 +60,28 @@ class _Block:
         return fused
 
 
-def fuse_circuit(circuit: list, max_qubits: int = 4, n_qubits: int | None = None) -> list:
+MAX_LEGS = 6      # qsv_apply_kq takes matrices on at most six qubits (include/qsv.h)
+
+
+def _conserves(gate: Gate, qubit: int) -> bool:
+    """True if ``gate`` never flips ``qubit`` (a control or a diagonal leg): on a sharded register such a leg costs
+    nothing when the qubit is a rank bit -- each rank applies the sub-block its own bit selects."""
+    from .distributed import _leg_is_block_diagonal
+
+    if qubit not in gate.indices:
+        return True
+    return _leg_is_block_diagonal(np.asarray(gate.matrix, dtype=np.complex128), len(gate.indices),
+                                  list(gate.indices).index(qubit))
+
+
+def fuse_circuit(circuit: list, max_qubits: int = 4, n_qubits: int | None = None, remote=()) -> list:
     """Return an equivalent circuit in which runs of plain gates are merged into blocks of <= ``max_qubits`` qubits.
+
+    ``remote``: qubits that sit on rank bits of a sharded register (``ShardedState.remote_qubits()``).  A remote
+    qubit that every gate of a block conserves does not count towards the block size (the shard-local matrix does
+    not contain it), and a gate that *mixes* a remote qubit is never merged into a block that only conserved it so
+    far -- the block can run without an exchange, the gate cannot, and merging would make the whole block wait for
+    the qubit to be brought in.
 
     ``n_qubits`` (the register size) makes the scheduler cost-aware: a 5-qubit block whose qubits include more than one
     of the six least significant ones runs on the transposed variants of ``k_dense_big<5>`` at one wave per SIMD
@@ -71,11 +91,21 @@ def fuse_circuit(circuit: list, max_qubits: int = 4, n_qubits: int | None = None
     out: list = []
     open_blocks: list[_Block] = []
 
-    def allowed(union) -> bool:
-        if len(union) <= min(max_qubits, 4) or n_qubits is None:
-            return len(union) <= max_qubits
+    remote = frozenset(remote)
+
+    def allowed(union, block_gates, gate) -> bool:
+        if len(union) > MAX_LEGS:
+            return False
+        seen = set().union(*(g.indices for g in block_gates))
+        conserved = {q for q in union & remote if all(_conserves(g, q) for g in block_gates)}
+        mixed_now = {q for q in gate.indices if q in remote and not _conserves(gate, q)}
+        if mixed_now & conserved & seen:
+            return False             # the new gate mixes a rank bit the block only conserved so far
+        size = len(union) - len(conserved - mixed_now)
+        if size <= min(max_qubits, 4) or n_qubits is None:
+            return size <= max_qubits
         low = sum(1 for q in union if n_qubits - 1 - q < 6)      # qubits that are lane bits of the kernels
-        return len(union) <= max_qubits and low <= 1
+        return size <= max_qubits and low <= 1
 
     def flush(blocks):
         for b in blocks:
@@ -85,13 +115,13 @@ def fuse_circuit(circuit: list, max_qubits: int = 4, n_qubits: int | None = None
     for gate in circuit:
         plain = isinstance(gate, Gate) and not isinstance(gate, (M, Insert)) and gate.matrix is not None \
             and gate.matrix.shape[0] == gate.matrix.shape[1]
-        if not plain or len(gate.indices) > max_qubits:
+        if not plain or len(gate.indices) > min(max_qubits, MAX_LEGS):
             flush(list(open_blocks))
             out.append(gate)
             continue
         touched = [b for b in open_blocks if set(b.qubits) & set(gate.indices)]
         union = set(gate.indices).union(*(b.qubits for b in touched))
-        if touched and allowed(union):
+        if touched and allowed(union, [g for b in touched for g in b.gates], gate):
             first = touched[0]
             for other in touched[1:]:
                 first.merge(other)

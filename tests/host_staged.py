@@ -2,7 +2,8 @@
 
 RCCL refuses two ranks on one device, and the development box has one GPU.  This subclass lets several ranks share
 that GPU -- HBM shards, HIP kernels, the real ``DeviceState`` engine -- by overriding only the collectives
-(``_exchange``, ``_allreduce_sum``, ``_allgather_shards``); everything else is ``ShardedState`` as shipped.
+(``_p2p``, ``_allreduce_sum``, ``_allgather_shards``); everything else -- the slicing of the shard into pieces, the two-slice staging buffer, the copies into place, all on
+device tensors -- is ``ShardedState`` as shipped.
 """
 from __future__ import annotations
 
@@ -13,12 +14,21 @@ from quantum_computations_amd.distributed import ShardedState
 
 
 class HostStagedShardedState(ShardedState):
-    def _exchange(self, send, recv, peer):
-        send_h, recv_h = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
-        ops = [dist.P2POp(dist.isend, send_h, peer), dist.P2POp(dist.irecv, recv_h, peer)]
-        for work in dist.batch_isend_irecv(ops):
-            work.wait()
-        recv.copy_(recv_h)
+    def _p2p(self, sends, recvs):
+        send_h = [(peer, t.cpu()) for peer, t in sends]
+        recv_h = [(peer, torch.empty(t.shape, dtype=t.dtype)) for peer, t in recvs]
+        ops = [dist.P2POp(dist.isend, torch.view_as_real(t), peer) for peer, t in send_h]
+        ops += [dist.P2POp(dist.irecv, torch.view_as_real(t), peer) for peer, t in recv_h]
+        works = dist.batch_isend_irecv(ops)
+
+        class _Step:
+            @staticmethod
+            def wait():
+                for w in works:
+                    w.wait()
+                for (_, dev_t), (_, host_t) in zip(recvs, recv_h):
+                    dev_t.copy_(host_t)
+        return _Step
 
     def _allreduce_sum(self, values):
         t = torch.tensor(values, dtype=torch.float64)

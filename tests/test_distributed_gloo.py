@@ -35,6 +35,14 @@ def run_workers(world: int, *extra: str, timeout: int = 600) -> str:
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_register_matches_oracle(world):
-    """world 2: direct send/recv pairs; world 4 and 8: the two-phase all-to-all (multi-path) exchange."""
-    out = run_workers(world, "--backend", "gloo", "--qubits", "9" if world < 8 else "10")
+    """world 2: pairwise half-shard swaps; world 4 and 8: all rank bits in one all-to-all.  The staging piece is cut
+    to 8 amplitudes so that every exchange runs the multi-slice, double-buffered loop the 1 GiB default only reaches
+    on registers of 32+ qubits."""
+    out = run_workers(world, "--backend", "gloo", "--qubits", "9" if world < 8 else "10", "--chunk-amps", "8")
     assert f"dist_worker ok: world={world}" in out
+    assert "chunk_amps=8" in out
+
+
+def test_default_chunk_single_slice():
+    out = run_workers(2, "--backend", "gloo", "--qubits", "8")
+    assert "dist_worker ok: world=2" in out and f"chunk_amps={1 << 26}" in out

@@ -66,6 +66,34 @@ def test_order_of_gates_sharing_a_qubit_is_kept():
         assert np.max(np.abs(oracle_run(fuse_circuit(gates, k), ket) - oracle_run(gates, ket))) < 1e-12
 
 
+def test_rank_bits_a_block_only_conserves_are_free_and_never_pulled_in():
+    """Fusion on a sharded register (``remote`` = qubits on rank bits): a remote control / diagonal leg does not count
+    towards the block size, and a gate that mixes a remote qubit does not join a block that merely conserved it."""
+    rng = np.random.default_rng(3)
+    u4 = lambda: W.haar_unitary(4, rng)
+    # qubit 0 is remote and only ever a control: 4 local legs + the free remote one fit a 4-qubit cap
+    gates = [G.CZ(0, 3), G.Gate([3, 4], u4()), G.CX(0, 5), G.Gate([5, 6], u4()), G.Gate([4, 5], u4())]
+    fused = fuse_circuit(gates, 4, remote=[0])
+    assert len(fused) == 1 and sorted(fused[0].indices) == [0, 3, 4, 5, 6]
+    assert len(fuse_circuit(gates, 4)) > 1                       # without the hint the union is 5 > 4 qubits
+    # H(0) mixes the rank bit: it must not drag the block (which runs without any exchange) behind an exchange
+    fused = fuse_circuit(gates + [G.H(0), G.CZ(0, 3)], 5, remote=[0])
+    assert [sorted(g.indices) for g in fused] == [[0, 3, 4, 5, 6], [0, 3]]
+    assert [len(getattr(g, "sources", [g])) for g in fused] == [5, 2]
+    # never more legs than the library's k-qubit entry point takes, however many of them are free
+    many = [G.CZ(r, 4 + r) for r in range(4)] + [G.Gate([4, 5], u4()), G.Gate([6, 7], u4()), G.Gate([5, 6], u4())]
+    assert all(len(g.indices) <= 6 for g in fuse_circuit(many, 5, remote=[0, 1, 2, 3]))
+    # and it stays an exact rewrite
+    n = 8
+    ops = W.random_circuit(n, 150, 17)
+    gates = W.to_gates(ops)
+    ket = W.random_ket(n, 17)
+    for remote in ([0], [0, 1, 2]):
+        fused = fuse_circuit(gates, 5, n_qubits=n, remote=remote)
+        assert sum(len(getattr(g, "sources", [g])) for g in fused) == len(gates)
+        assert np.max(np.abs(oracle_run(fused, ket) - oracle_run(gates, ket))) < 1e-12
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fuse", [2, 3, 4, 5])
 def test_simulator_with_fusion_matches_reference(golden, fuse):
