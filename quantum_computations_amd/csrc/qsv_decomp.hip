@@ -1400,6 +1400,7 @@ int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream
         uint64_t count = 0;
     };
     static Probes cache[16];
+    if (device < 0 || device >= 16) return QSV_UNDECIDED;  // no probe cache for this ordinal: take the exact route
     Probes &probes = cache[device];
     if (!probes.partials && hipMalloc(reinterpret_cast<void **>(&probes.partials), sizeof(double) * 256) != hipSuccess) {
         probes.partials = nullptr;

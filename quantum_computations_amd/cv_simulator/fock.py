@@ -30,13 +30,36 @@ def phase_matrix(d: int, angle: float) -> np.ndarray:
     return np.exp(-1j * angle * np.arange(d))          # diagonal: exp(-i angle n)
 
 
-def beamsplitter_matrix(d: int, theta: float, phi: float = 0.0) -> np.ndarray:
-    """exp(theta (e^{i phi} a b^dagger - e^{-i phi} a^dagger b)) on two d-level modes: a (d^2 x d^2) matrix, row / column
-    index n_a * d + n_b.  It conserves n_a + n_b, so every row has at most d non-zero entries."""
-    a = np.kron(annihilation(d), np.identity(d))
-    b = np.kron(np.identity(d), annihilation(d))
-    gen = theta * (np.exp(1j * phi) * a @ b.conj().T - np.exp(-1j * phi) * a.conj().T @ b)
-    return expm(gen)
+def beamsplitter_blocks(d: int, theta: float, phi: float = 0.0):
+    """The beam splitter exp(theta (e^{i phi} a b^dagger - e^{-i phi} a^dagger b)) on two d-level modes, as its
+    2d - 1 photon-number blocks ``[(plane_indices, block_matrix), ...]``, ``plane_indices = n_a * d + n_b`` with
+    ``n_a + n_b = N``.  The truncated generator only connects |n_a, n_b> with |n_a -+ 1, n_b +- 1>, so it is block
+    diagonal in N and its exponential is the exponential of each (at most d x d, tridiagonal) block -- 63 small
+    ``expm`` calls for d = 32 instead of one on a 1024 x 1024 matrix (7 s)."""
+    blocks = []
+    for total in range(2 * d - 1):
+        na = np.arange(max(0, total - d + 1), min(d, total + 1))
+        nb = total - na
+        gen = np.zeros((na.size, na.size), dtype=np.complex128)
+        # a b^dagger |n_a, n_b> = sqrt(n_a (n_b + 1)) |n_a - 1, n_b + 1>: column j -> row j - 1
+        up = np.sqrt(na[1:] * (nb[1:] + 1.0))
+        gen[np.arange(na.size - 1), np.arange(1, na.size)] = theta * np.exp(1j * phi) * up
+        gen[np.arange(1, na.size), np.arange(na.size - 1)] = -theta * np.exp(-1j * phi) * up
+        blocks.append(([int(a * d + b) for a, b in zip(na, nb)], expm(gen)))
+    return blocks
+
+
+def beamsplitter_matrix(d: int, theta: float, phi: float = 0.0, *, dense_expm: bool = False) -> np.ndarray:
+    """The same operator as a (d^2 x d^2) matrix, row / column index n_a * d + n_b.  It conserves n_a + n_b, so every
+    row has at most d non-zero entries.  ``dense_expm`` exponentiates the full generator instead (cross-check)."""
+    if dense_expm:
+        a = np.kron(annihilation(d), np.identity(d))
+        b = np.kron(np.identity(d), annihilation(d))
+        return expm(theta * (np.exp(1j * phi) * a @ b.conj().T - np.exp(-1j * phi) * a.conj().T @ b))
+    out = np.zeros((d * d, d * d), dtype=np.complex128)
+    for idx, block in beamsplitter_blocks(d, theta, phi):
+        out[np.ix_(idx, idx)] = block
+    return out
 
 
 def sparse_rows(matrix: np.ndarray, tol: float = 0.0):
@@ -110,6 +133,9 @@ class BS(TwoModeGate):
 
     def apply(self, state: FockState, **_):
         theta = -self.arg if self.dagger else self.arg
+        if self.method == "blocks":
+            state.reg.apply_two_mode_blocks(beamsplitter_blocks(state.d, theta), self.index1, self.index2)
+            return
         m = beamsplitter_matrix(state.d, theta)
         if self.method == "dense":
             state.reg.apply_two_mode(m, self.index1, self.index2)
@@ -117,4 +143,4 @@ class BS(TwoModeGate):
             cols, vals = sparse_rows(m, tol=1e-300)
             state.reg.apply_two_mode_gather(cols, vals, self.index1, self.index2)
         else:
-            state.reg.apply_two_mode_blocks(photon_number_blocks(m, state.d), self.index1, self.index2)
+            raise ValueError(f"unknown method {self.method!r}")

@@ -296,15 +296,16 @@ class DeviceState:
 class QuditState:
     """``n_modes`` d-level modes, dense complex128, mode 0 slowest (cv_simulator-style mode indices)."""
 
-    def __init__(self, handle: C.c_void_p):
+    def __init__(self, handle: C.c_void_p, device: int = 0):
         self._h = handle
+        self.device = device          # HIP device ordinal the register lives on
 
     @classmethod
     def zeros(cls, n_modes: int, d: int, device: int = 0) -> "QuditState":
         """All modes in level 0 (vacuum in a Fock basis)."""
         h = C.c_void_p()
         _lib.call("qsv_create_qudit", int(n_modes), int(d), int(device), C.byref(h))
-        return cls(h)
+        return cls(h, int(device))
 
     @classmethod
     def from_numpy(cls, tensor: np.ndarray, device: int = 0) -> "QuditState":
@@ -339,6 +340,12 @@ class QuditState:
         out = np.empty(d ** n, dtype=np.complex128)
         _lib.call("qsv_download", self._h, _ptr(out), 0, out.size)
         return out.reshape((d,) * n)
+
+    def upload(self, tensor: np.ndarray) -> None:
+        """Overwrite the register with ``tensor`` (shape ``(d,) * n_modes`` or flat, mode 0 slowest)."""
+        n, d = self.dims
+        buf = _cbuf(tensor, d ** n)
+        _lib.call("qsv_upload", self._h, _ptr(buf), 0, buf.size)
 
     def sync(self) -> None:
         _lib.call("qsv_sync", self._h)
@@ -407,7 +414,7 @@ class QuditState:
 
     def copy(self) -> "QuditState":
         n, d = self.dims
-        other = QuditState.zeros(n, d)
+        other = QuditState.zeros(n, d, self.device)
         _lib.call("qsv_copy", other._h, self._h)
         return other
 

@@ -161,6 +161,29 @@ class ShardedState:
             st.local.set_basis(0)
         return st
 
+    def set_basis(self, index: int) -> None:
+        """The basis state ``|index>`` (reference bit order); the layout goes back to the identity map."""
+        if not 0 <= index < (1 << self.n):
+            raise ValueError("basis index out of range")
+        self.phys = list(range(self.n))
+        if index >> self.n_local == self.rank:
+            self.local.set_basis(index & ((1 << self.n_local) - 1))
+        else:
+            self.local.apply_scale(0.0)
+
+    def warm_up_links(self) -> None:
+        """One tiny message to and from every other rank: RCCL sets up its per-peer channels on first use, which
+        would otherwise be charged to the first exchange of a circuit."""
+        if self._dist is None or self.world == 1:
+            return
+        import torch
+
+        out = torch.zeros(self.world, dtype=self.buf.dtype, device=self.buf.device)
+        inc = torch.empty_like(out)
+        others = [r for r in range(self.world) if r != self.rank]
+        self._p2p([(r, out[r:r + 1]) for r in others], [(r, inc[r:r + 1]) for r in others]).wait()
+        self._allreduce_sum([0.0])
+
     def fill_random(self, seed: int) -> None:
         n2 = self.local.fill_random(seed, index_offset=self.rank << self.n_local, normalise=False)
         self.local.apply_scale(1.0 / float(np.sqrt(self._allreduce_sum([n2])[0])))

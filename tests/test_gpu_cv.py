@@ -208,3 +208,41 @@ def test_fock_path_cfg4_small():
         want = CO.apply_axis_diag(want, fock.phase_matrix(d, 0.3), mode)
     assert maxdiff(st.contract(), want) < 1e-12
     assert abs(st.norm() - np.linalg.norm(want)) < 1e-12
+
+
+@pytest.mark.parametrize("n_modes", [3, 4])
+def test_fock_path_cfg4_at_cutoff_32(n_modes):
+    """BASELINE config 4 at its own cutoff d = 32 (3 and 4 of its 6 modes: 32 Ki / 1 Mi amplitudes), on a random
+    register.  d = 32 makes the register a 5-bit-per-mode qubit register, so this runs the instantiations the
+    6-mode configuration launches: S through ``k_dense_big<5, KL>`` with KL = 5 (last mode: all target bits inside a
+    wavefront), KL = 1 (second to last: one lane bit) and KL = 0 (every other mode); the Fock beam splitter through the
+    block kernels of ``qsv_apply_mode2_blocks`` on the last pair (R = 1: the plane is contiguous), the pair before it
+    (R = 32) and earlier pairs (R >= 1024), with the legs in either order."""
+    d = 32
+    rng = np.random.default_rng(320 + n_modes)
+    psi = rng.standard_normal((d,) * n_modes) + 1j * rng.standard_normal((d,) * n_modes)
+    psi /= np.linalg.norm(psi)
+    st = fock.FockState(n_modes, d)
+    st.reg.upload(psi)
+    want = psi
+    bs = fock.beamsplitter_matrix(d, np.pi / 4)
+    for mode in range(n_modes):
+        r = 0.1 * (mode + 1)
+        fock.S(mode, r).apply(st)
+        want = CO.apply_axis(want, fock.squeeze_matrix(d, r), mode)
+    assert maxdiff(st.contract(), want) < 1e-12
+    pairs = [(i, i + 1) for i in range(n_modes - 1)] + [(n_modes - 1, n_modes - 2), (1, 0)]
+    for pair in pairs:
+        fock.BS(*pair, np.pi / 4).apply(st)
+        want = CO.apply_two_axes(want, bs, *pair)
+        assert maxdiff(st.contract(), want) < 1e-12, pair
+    # a beam splitter with a phase has complex blocks (the real-matrix fast paths must not be taken for it)
+    bs_c = fock.beamsplitter_blocks(d, 0.4, 0.9)
+    st.reg.apply_two_mode_blocks(bs_c, n_modes - 2, n_modes - 1)
+    want = CO.apply_two_axes(want, fock.beamsplitter_matrix(d, 0.4, 0.9), n_modes - 2, n_modes - 1)
+    st.reg.apply_two_mode_blocks(bs_c, 0, 1)
+    want = CO.apply_two_axes(want, fock.beamsplitter_matrix(d, 0.4, 0.9), 0, 1)
+    fock.S(n_modes - 1, 0.3, 0.7).apply(st)                      # complex squeezing parameter on the lane-bit mode
+    want = CO.apply_axis(want, fock.squeeze_matrix(d, 0.3, 0.7), n_modes - 1)
+    assert maxdiff(st.contract(), want) < 1e-12
+    assert abs(st.norm() - np.linalg.norm(want)) < 1e-12

@@ -484,8 +484,10 @@ def test_33_qubit_register_uses_64_bit_indices():
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_state_on_one_gpu(world):
     from test_distributed_gloo import run_workers
-    out = run_workers(world, "--backend", "gloo-gpu", "--qubits", "12")
-    assert f"dist_worker ok: world={world} backend=gloo-gpu" in out
+    # staging pieces of 64 amplitudes: every exchange runs the multi-slice, double-buffered loop on device tensors
+    # (slicing of the shard, two-slice staging buffer, copies into place); only the send/recv itself is host-staged
+    out = run_workers(world, "--backend", "gloo-gpu", "--qubits", "12", "--chunk-amps", "64")
+    assert f"dist_worker ok: world={world} backend=gloo-gpu" in out and "chunk_amps=64" in out
 
 
 # ---- d-level modes --------------------------------------------------------------------------------------------
