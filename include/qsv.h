@@ -52,8 +52,14 @@ enum {
     QSV_OPT_NONTEMPORAL = 4, /* 1 (default): nontemporal loads/stores in the streaming kernels */
     QSV_OPT_ITEM_STRIDE_BIT = 5, /* log2 of the distance (in work items) between the items one thread keeps in
                                     flight when unroll > 1; default 8 = consecutive 4 KiB tiles */
-    QSV_OPT_TILE_REGIONS = 6 /* tile order of the streaming kernels: R > 1 walks R contiguous regions of the register
+    QSV_OPT_TILE_REGIONS = 6, /* tile order of the streaming kernels: R > 1 walks R contiguous regions of the register
                                 side by side (8 = one per XCD), 0 = plain order, -1 (default) = per-kernel choice */
+    QSV_OPT_KQ_VARIANT = 7,  /* qsv_apply_kq, k = 3..5, how target bits below 6 reach the registers: 0 (default) =
+                                the measured best per case, 1 = wave-shuffle butterflies, 2 = no exchange (per-thread
+                                strided access), 3 = line-granular exchange (address arithmetic for bits 3..5, LDS for
+                                bits 0..2).  Same results; for measurements */
+    QSV_OPT_PLANE_KERNEL = 8 /* qsv_apply_mode2_blocks on the last two modes with real blocks: 1 (default) = one
+                                workgroup per (d x d) plane staged through LDS, 0 = one thread per plane */
 };
 
 typedef struct qsv_state qsv_state;

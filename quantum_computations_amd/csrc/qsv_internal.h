@@ -77,6 +77,10 @@ struct qsv_state {
     int nontemporal = 1;
     int ubit = 8;
     int remap = -1;                   // tile order: -1 = per-kernel default, 0 = plain, R = regions
+    int kq_variant = 0;               // k = 3..5 gates: 0 = per-case choice, 1 = wave shuffles (k_dense_big<K, KL>),
+                                      // 2 = no transpose (per-thread strided access), 3 = line-granular (k_dense_lds)
+    int plane_kernel = 1;             // block-diagonal two-mode operators on the last two modes: 1 = workgroup-per-plane
+                                      // form (k_mode2_plane), 0 = plane-per-thread form (k_mode2_blocks<64>)
     char last_kernel[96] = "";        // name of the most recent gate kernel launched (qsv_last_kernel)
 };
 

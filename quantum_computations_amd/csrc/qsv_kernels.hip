@@ -361,6 +361,109 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_dense_big(amp_t *__restrict__ a, 
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------------
+// Register-blocked k-qubit dense gate with target bits below 6, second form: the low target bits are brought into
+// registers WITHOUT wave shuffles and without a second register array for the results.
+//
+// A low target bit L still gets a stand-in high bit E (as above), so that whatever a wave-instruction touches is made
+// of whole 128-byte lines.  But only the bits 0..2 of the index live INSIDE a line.  For a target on lane bit 3, 4 or
+// 5 ("A" bits) the exchange of roles between L and E is pure address arithmetic: lane l fetches, for register value
+// v, the amplitude in row E := (bit L of l), column (l with bit L := v).  Each wave-instruction then reads 8 whole
+// lines from 2^|A| rows instead of 8 consecutive ones -- the same number of lines -- and the thread owns both values
+// of bit L at once.  Nothing moves between lanes.
+// Targets on lane bits 0..2 ("B" bits, at most three) need a real transpose among the 2^|B| neighbouring lanes that
+// share a line.  It goes through LDS, 2^|B| rows of 64 amplitudes (at most 8 KiB per wave) at a time: lane l writes
+// row s at column l ^ dep(s) and reads row (its own B bits) at column l ^ dep(t) -- an XOR swizzle that makes both
+// directions conflict-free for 16-byte accesses (a 16-lane group of ds_read_b128 always sees 16 different columns
+// mod 16, and rows are 64 slots apart).  Results take the same road back one row group at a time, straight from the
+// accumulator, so the thread holds the 2^K inputs (K = 5: 128 VGPRs) and nothing else: 3 waves per SIMD instead of
+// one, and the next wave's loads overlap this wave's arithmetic.
+// ----------------------------------------------------------------------------------------------------
+struct LdsArgs {
+    uint64_t W;
+    int32_t nins;
+    uint8_t pos[2 * QSV_MAX_K];  // ascending: high targets and stand-in bits
+    uint64_t or_mask;            // unused (0); lets deposit() serve this struct too
+    uint64_t w0;                 // first work item of this launch
+    uint32_t regions;            // tile order (see GateArgs::remap)
+    uint32_t amask;              // lane bits of the A targets
+    int32_t abit[3], aE[3];      // A target j: lane bit, stand-in bit
+    int32_t na;                  // number of A targets
+    uint32_t bdep[8];            // dep(v): the KB bits of v spread onto the lane bits of the B targets
+    uint32_t bmask;              // lane bits of the B targets
+};
+
+// The LDS rows are private to a wave (a wave exchanges data with itself only), and the LDS executes one wave's
+// instructions in order: no workgroup barrier is needed, only the compiler must keep the program order of the
+// accesses (it does: they may alias) -- wave_sync() marks the spots.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
+template <int K, int KB, bool NT, bool REALM, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_dense_lds(amp_t *__restrict__ a, const LdsArgs g,
+                                                     const double *__restrict__ M,
+                                                     const uint64_t *__restrict__ hoff) {
+    constexpr int D = 1 << K, NB = 1 << KB;
+    __shared__ amp_t tiles[KB > 0 ? NB * BLOCK : 1];
+    amp_t *tile = tiles + (KB > 0 ? NB * 64 * (threadIdx.x >> 6) : 0);
+    const uint64_t tile_id = (g.regions > 1 && gridDim.x % g.regions == 0)
+                                 ? (blockIdx.x % g.regions) * (gridDim.x / g.regions) + blockIdx.x / g.regions
+                                 : blockIdx.x;
+    const uint64_t w = g.w0 + tile_id * static_cast<uint64_t>(BLOCK) + threadIdx.x;
+    if (w >= g.W) return;  // W and w0 are multiples of 64: whole waves leave together
+    const uint32_t lane = threadIdx.x & 63;
+    // row of this lane: its A bits move from the column to the stand-in bits
+    uint64_t base = deposit(w, g) & ~static_cast<uint64_t>(g.amask);
+    for (int j = 0; j < g.na; ++j) base |= static_cast<uint64_t>((lane >> g.abit[j]) & 1u) << g.aE[j];
+    amp_t x[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[c] = ld<NT>(a + base + hoff[c]);
+    uint32_t my_row = 0;  // this lane's B bits, as a row number
+    if constexpr (KB > 0) {
+#pragma unroll
+        for (int v = 1; v < NB; ++v)
+            if ((lane & g.bmask) == g.bdep[v]) my_row = v;
+#pragma unroll
+        for (int o = 0; o < D / NB; ++o) {
+            wave_sync();
+#pragma unroll
+            for (int s = 0; s < NB; ++s) tile[s * 64 + (lane ^ g.bdep[s])] = x[o * NB + s];
+            wave_sync();
+#pragma unroll
+            for (int t = 0; t < NB; ++t) x[o * NB + t] = tile[my_row * 64 + (lane ^ g.bdep[t])];
+        }
+    }
+    // every thread now owns one complete group; rows of the matrix come through scalar loads
+#pragma unroll 1
+    for (int o = 0; o < D / NB; ++o) {
+        if constexpr (KB > 0) wave_sync();
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const int r = o * NB + t;
+            amp_t acc = {0.0, 0.0};
+            if constexpr (REALM) {
+                const double *row = M + D * r;
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    acc.x = fma(row[c], x[c].x, acc.x);
+                    acc.y = fma(row[c], x[c].y, acc.y);
+                }
+            } else {
+                const double *row = M + 2 * D * r;
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc = cfma(cplx{row[2 * c], row[2 * c + 1]}, x[c], acc);
+            }
+            if constexpr (KB > 0) tile[my_row * 64 + (lane ^ g.bdep[t])] = acc;
+            else st<NT>(a + base + hoff[r], acc);  // in place: every input of this group is already in registers
+        }
+        if constexpr (KB > 0) {
+            wave_sync();
+#pragma unroll
+            for (int s = 0; s < NB; ++s) st<NT>(a + base + hoff[o * NB + s], tile[s * 64 + (lane ^ g.bdep[s])]);
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------
 // Reductions, measurement, insertion, permutation, fills.
 // ----------------------------------------------------------------------------------------------------
@@ -887,17 +990,42 @@ static int dispatch_big(qsv_state *st, int KL, bool nt, dim3 gd, const BigArgs &
     return check_launch();
 }
 
+
+template <int K, int KB, int BLOCK>
+static void launch_lds_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const LdsArgs &g, const uint64_t *dev_off) {
+    const dim3 bd(BLOCK);
+    if (nt) {
+        if (realm) hipLaunchKernelGGL((k_dense_lds<K, KB, true, true, BLOCK>), gd, bd, 0, st->stream, st->data, g, st->dev_matrix, dev_off);
+        else hipLaunchKernelGGL((k_dense_lds<K, KB, true, false, BLOCK>), gd, bd, 0, st->stream, st->data, g, st->dev_matrix, dev_off);
+    } else {
+        if (realm) hipLaunchKernelGGL((k_dense_lds<K, KB, false, true, BLOCK>), gd, bd, 0, st->stream, st->data, g, st->dev_matrix, dev_off);
+        else hipLaunchKernelGGL((k_dense_lds<K, KB, false, false, BLOCK>), gd, bd, 0, st->stream, st->data, g, st->dev_matrix, dev_off);
+    }
+}
+
+template <int K, int BLOCK>
+static int dispatch_lds(qsv_state *st, int KB, bool nt, bool realm, dim3 gd, const LdsArgs &g, const uint64_t *dev_off) {
+    switch (KB) {
+        case 0: launch_lds_kernel<K, 0, BLOCK>(st, nt, realm, gd, g, dev_off); break;
+        case 1: launch_lds_kernel<K, 1, BLOCK>(st, nt, realm, gd, g, dev_off); break;
+        case 2: launch_lds_kernel<K, 2, BLOCK>(st, nt, realm, gd, g, dev_off); break;
+        default: launch_lds_kernel<K, 3, BLOCK>(st, nt, realm, gd, g, dev_off); break;
+    }
+    return check_launch();
+}
+
 // k = 3..5 on any register with at least k qubits.  bits[j] = bit position of matrix leg j (leg 0 most significant).
 static int launch_dense_big(qsv_state *st, int k, const int *bits, const double *m_user) {
     const int D = 1 << k;
     std::vector<int> high, low;
     for (int j = 0; j < k; ++j) (bits[j] >= QSV_LANE_BITS ? high : low).push_back(bits[j]);
+    std::sort(low.begin(), low.end());  // bits 0..2 (inside a 128-byte line) first, then bits 3..5
     int KL = static_cast<int>(low.size());
     // stand-in bits for the low targets: the lowest free bits >= 6 (needs n >= k + 6)
     std::vector<int> standin;
     for (int b = QSV_LANE_BITS; b < st->n && static_cast<int>(standin.size()) < KL; ++b)
         if (std::find(high.begin(), high.end(), b) == high.end()) standin.push_back(b);
-    const bool transposed = KL > 0 && static_cast<int>(standin.size()) == KL;
+    const bool transposed = KL > 0 && static_cast<int>(standin.size()) == KL && st->kq_variant != 2;
     if (!transposed) {  // all targets high, or a register too small to transpose: lanes = lowest free bits
         high.assign(bits, bits + k);
         low.clear();
@@ -905,17 +1033,24 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
         KL = 0;
     }
     const int KH = k - KL;
+    bool real_matrix = true;
+    for (int i = 0; i < D * D && real_matrix; ++i) real_matrix = m_user[2 * i + 1] == 0.0;
+    // Which form (MI355X, n = 28, profiles/r02_sweep_kq_kernels.txt): k = 5 with low targets -> the line-granular
+    // kernel (4.9-5.2 TB/s at every placement; the shuffle form drops to 2.1-4.4 there); k = 5 real matrices ->
+    // the same kernel's two-FMA arithmetic (5.4-5.8 TB/s); k = 3, 4 and k = 5 on high bits -> the shuffle form
+    // (its butterflies are cheap up to 16 amplitudes per thread: 5.6-6.0 TB/s).  QSV_OPT_KQ_VARIANT overrides.
+    const bool fits = (st->amps >> k) >= 64 && (st->amps >> k) % 64 == 0;
+    const bool use_lds = fits && (st->kq_variant == 3 || (st->kq_variant == 0 && k == 5 && (KL > 0 || real_matrix)));
+    int KB = 0;
+    for (int b : low) KB += b < 3;
     // register index c = (h << KL) | t: h bit i <-> high[i], t bit j <-> low[j] (stored at stand-in bit standin[j])
-    BigArgs g;
-    std::memset(&g, 0, sizeof(g));
     std::vector<uint64_t> off(D, 0);
     for (int c = 0; c < D; ++c) {
         for (int i = 0; i < KH; ++i)
             if ((c >> (KL + i)) & 1) off[c] |= 1ull << high[i];
         for (int j = 0; j < KL; ++j)
-            if ((c >> j) & 1) off[c] |= 1ull << standin[j];
+            if ((c >> j) & 1) off[c] |= 1ull << ((use_lds && low[j] >= 3) ? low[j] : standin[j]);
     }
-    for (int j = 0; j < KL; ++j) g.lbit[j] = low[j];
     auto user_index = [&](int c) {  // kernel register index -> index of the caller's matrix
         int u = 0;
         for (int leg = 0; leg < k; ++leg) {
@@ -928,24 +1063,66 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
         }
         return u;
     };
-    std::vector<double> m(2ull * D * D);
+    const bool realm = use_lds && real_matrix;
+    std::vector<double> m(realm ? static_cast<size_t>(D) * D : 2ull * D * D);
     for (int r = 0; r < D; ++r)
         for (int c = 0; c < D; ++c) {
             const int ur = user_index(r), uc = user_index(c);
-            m[2 * (r * D + c)] = m_user[2 * (ur * D + uc)];
-            m[2 * (r * D + c) + 1] = m_user[2 * (ur * D + uc) + 1];
+            if (realm) {
+                m[r * D + c] = m_user[2 * (ur * D + uc)];
+            } else {
+                m[2 * (r * D + c)] = m_user[2 * (ur * D + uc)];
+                m[2 * (r * D + c) + 1] = m_user[2 * (ur * D + uc) + 1];
+            }
         }
-    const size_t mbytes = sizeof(double) * m.size(), obytes = sizeof(uint64_t) * D;
+    const size_t mbytes = sizeof(double) * 2ull * D * D, obytes = sizeof(uint64_t) * D;
     int rc = qsvk_ensure_matrix(st, mbytes + obytes);
     if (rc) return rc;
     uint64_t *dev_off = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(st->dev_matrix) + mbytes);
-    QSV_HIP(hipMemcpyAsync(st->dev_matrix, m.data(), mbytes, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipMemcpyAsync(st->dev_matrix, m.data(), sizeof(double) * m.size(), hipMemcpyHostToDevice, st->stream));
     QSV_HIP(hipMemcpyAsync(dev_off, off.data(), obytes, hipMemcpyHostToDevice, st->stream));
     QSV_HIP(hipStreamSynchronize(st->stream));  // both sources are pageable host memory that dies at return
-    g.W = st->amps >> k;
     std::vector<int> ins(high);
     ins.insert(ins.end(), standin.begin(), standin.end());
     std::sort(ins.begin(), ins.end());
+    const uint64_t W = st->amps >> k;
+    if (use_lds) {
+        LdsArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.W = W;
+        g.nins = static_cast<int>(ins.size());
+        for (size_t j = 0; j < ins.size(); ++j) g.pos[j] = static_cast<uint8_t>(ins[j]);
+        for (int j = 0; j < KL; ++j) {
+            if (low[j] >= 3) {
+                g.abit[g.na] = low[j];
+                g.aE[g.na] = standin[j];
+                g.amask |= 1u << low[j];
+                ++g.na;
+            } else {
+                g.bmask |= 1u << low[j];
+            }
+        }
+        for (int v = 0; v < (1 << KB); ++v)
+            for (int j = 0; j < KB; ++j)
+                if ((v >> j) & 1) g.bdep[v] |= 1u << low[j];
+        const bool nt = st->nontemporal != 0;  // every wave-instruction touches whole 128-byte lines
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_lds<%d, %d, %s, %s>", k, KB, nt ? "true" : "false",
+                 realm ? "true" : "false");
+        g.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : 8;
+        const uint64_t per_launch = 0x00ffffffull * QSV_BLOCK;  // an AQL dispatch counts work-items in 32 bits
+        for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
+            const dim3 gd(grid_for(std::min(per_launch, g.W - g.w0), QSV_BLOCK, 0));
+            const int rc2 = k == 3 ? dispatch_lds<3, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_off)
+                          : k == 4 ? dispatch_lds<4, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_off)
+                                   : dispatch_lds<5, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_off);
+            if (rc2) return rc2;
+        }
+        return QSV_OK;
+    }
+    BigArgs g;
+    std::memset(&g, 0, sizeof(g));
+    for (int j = 0; j < KL; ++j) g.lbit[j] = low[j];
+    g.W = W;
     g.nins = static_cast<int>(ins.size());
     for (size_t j = 0; j < ins.size(); ++j) g.pos[j] = static_cast<uint8_t>(ins[j]);
     // partial-line nontemporal accesses are slow: use them only when every access is a full 1 KiB per wave

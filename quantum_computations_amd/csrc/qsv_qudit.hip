@@ -171,7 +171,7 @@ constexpr int MAX_BLOCK = 32;
 // flight and short dependency chains.  Workgroup order: all blocks of one group of planes are dealt to the same XCD
 // back to back, so when the plane group is not contiguous in memory (R < 8: neighbouring lanes are up to 16 KiB apart and
 // every 128-byte line is shared by several anti-diagonals) the re-touched lines are served by that XCD's L2.
-template <int THREADS>
+template <int THREADS, bool REALM>
 __global__ __launch_bounds__(THREADS) void k_mode2_blocks(amp_t *__restrict__ a, uint64_t L, int d, uint64_t Mid,
                                                          uint64_t R, int nblocks, uint64_t groups,
                                                          const int32_t *__restrict__ sizes,
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(THREADS) void k_mode2_blocks(amp_t *__restrict__ a,
         amp_t *base = a + l * (R * d * Mid * d) + m * (R * d) + r;
         const int s = sizes[b];
         const uint64_t *off = plane_off + idx_start[b];
-        const double *M = mats + 2 * mat_start[b];
+        const double *M = mats + (REALM ? 1 : 2) * mat_start[b];  // real matrices are stored as one double per entry
         amp_t x[MAX_BLOCK];
 #pragma unroll
         for (int c = 0; c < MAX_BLOCK; ++c) {
@@ -202,13 +202,106 @@ __global__ __launch_bounds__(THREADS) void k_mode2_blocks(amp_t *__restrict__ a,
             else x[c] = amp_t{0.0, 0.0};
         }
         for (int row = 0; row < s; ++row) {
-            const double *mr = M + 2 * static_cast<size_t>(row) * s;
+            const double *mr = M + (REALM ? 1 : 2) * static_cast<size_t>(row) * s;
             amp_t acc = {0.0, 0.0};
 #pragma unroll
             for (int c = 0; c < MAX_BLOCK; ++c)
-                if (c < s) acc = cfma(cplx{mr[2 * c], mr[2 * c + 1]}, x[c], acc);
+                if (c < s) {
+                    if constexpr (REALM) {
+                        acc.x = fma(mr[c], x[c].x, acc.x);
+                        acc.y = fma(mr[c], x[c].y, acc.y);
+                    } else {
+                        acc = cfma(cplx{mr[2 * c], mr[2 * c + 1]}, x[c], acc);
+                    }
+                }
             if (THREADS == QSV_BLOCK) __builtin_nontemporal_store(acc, base + off[row]);
             else base[off[row]] = acc;
+        }
+    }
+}
+
+
+// Block-diagonal two-mode operator when the two modes are the LAST two (R = 1): the (d x d) plane is d^2 consecutive
+// amplitudes (16 KiB for d = 32) and a block's elements lie 16 * (d - 1) bytes apart -- every 128-byte line holds
+// amplitudes of eight different blocks.  The plane-per-thread form above then touches 16 bytes of 64 different lines per
+// wave-instruction, and lines written piecemeal by different workgroups leave the L2 half filled (measured in round 1:
+// 2.5x the algorithmic bytes written).  Here a 1024-thread workgroup owns whole planes instead:
+//   * thread t loads amplitude t of the plane batch (1 KiB per wave-instruction, three batches ahead) into LDS;
+//   * thread t is ALSO the owner of one output element e(t): it keeps that element's row of its block matrix in
+//     registers for the whole launch (real matrices: <= 32 doubles) and per plane reads the block's inputs from LDS --
+//     input k of a block sits a constant `stride` elements after input k-1, so the address is one register plus an
+//     immediate; threads of the same block read the same address (a broadcast, no bank conflict);
+//   * the result goes to a second LDS tile at its own place, and after a barrier thread t stores amplitude t of that
+//     tile: every global access of the kernel is a whole 1 KiB segment, every line is written exactly once.
+// Elements are dealt to threads in order of decreasing block size, so the waves of a workgroup have near-uniform trip
+// counts (sum over waves = 342 iterations per plane for d = 32 against 512 for the natural order).
+// Only for real block matrices (a complex row would need 128 VGPRs at 4 waves per SIMD); complex ones keep the form above.
+constexpr int PLANE_THREADS = 1024;
+
+struct PlaneArgs {
+    uint64_t batches;     // plane batches in the register
+    uint32_t batch_amps;  // amplitudes per batch (planes per batch x d^2), <= PLANE_THREADS
+    int32_t stride;       // elements between consecutive inputs of a block (may be negative)
+};
+
+template <int STRIDE, bool NT>  // STRIDE != 0: compile-time stride (LDS offsets become immediates); 0: g.stride
+__global__ __launch_bounds__(PLANE_THREADS) void k_mode2_plane(amp_t *__restrict__ a, const PlaneArgs g,
+                                                               const double *__restrict__ coef,   // [threads][MAX_BLOCK]
+                                                               const int32_t *__restrict__ rd0,   // [threads] first input
+                                                               const int32_t *__restrict__ wr,    // [threads] my output
+                                                               const int32_t *__restrict__ wave_trip) {
+    __shared__ amp_t in_t[PLANE_THREADS];
+    __shared__ amp_t out_t[PLANE_THREADS];
+    const int tid = threadIdx.x;
+    const bool active = static_cast<uint32_t>(tid) < g.batch_amps;
+    // lanes whose block is smaller than their wave's trip count multiply what they read past their block by 0.0:
+    // whatever that is must be finite (never-written tile slots would hold another kernel's leftovers)
+    in_t[tid] = amp_t{0.0, 0.0};
+    out_t[tid] = amp_t{0.0, 0.0};
+    double c[MAX_BLOCK];
+#pragma unroll
+    for (int k = 0; k < MAX_BLOCK; ++k) c[k] = coef[static_cast<size_t>(tid) * MAX_BLOCK + k];
+    const int nk = __builtin_amdgcn_readfirstlane(wave_trip[tid >> 6]);
+    const int stride = STRIDE != 0 ? STRIDE : g.stride;
+    const amp_t *src = in_t + rd0[tid];
+    amp_t *dst = out_t + wr[tid];
+    const uint64_t step = gridDim.x;
+    auto fetch = [&](uint64_t b) -> amp_t {
+        amp_t v = {0.0, 0.0};
+        if (active && b < g.batches) {
+            const amp_t *p = a + b * g.batch_amps + tid;
+            v = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+        return v;
+    };
+    amp_t g0 = fetch(blockIdx.x), g1 = fetch(blockIdx.x + step), g2 = fetch(blockIdx.x + 2 * step);
+    for (uint64_t b = blockIdx.x; b < g.batches; b += step) {
+        const amp_t cur = g0;
+        g0 = g1;
+        g1 = g2;
+        g2 = fetch(b + 3 * step);
+        if (active) in_t[tid] = cur;
+        __syncthreads();
+        amp_t acc = {0.0, 0.0};
+#pragma unroll
+        for (int k0 = 0; k0 < MAX_BLOCK; k0 += 4) {
+            if (k0 < nk) {  // wave-uniform; four LDS reads in flight per step (inputs past the trip count meet 0.0)
+                amp_t x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = src[(k0 + j) * stride];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc.x = fma(c[k0 + j], x[j].x, acc.x);
+                    acc.y = fma(c[k0 + j], x[j].y, acc.y);
+                }
+            }
+        }
+        if (active) *dst = acc;
+        __syncthreads();
+        if (active) {
+            amp_t *p = a + b * g.batch_amps + tid;
+            if (NT) __builtin_nontemporal_store(out_t[tid], p);
+            else *p = out_t[tid];
         }
     }
 }
@@ -440,6 +533,88 @@ int qsvq_mode2_gather(qsv_state *st, int mode0, int mode1, int nnz, const int32_
     return adopt(st, fresh);
 }
 
+
+constexpr int QSV_UNHANDLED = 1 << 20;  // internal: "this fast path does not apply, take the general one"
+
+// The R = 1 workgroup-per-plane form (k_mode2_plane).  `off[idx_start[b] + j]` is the plane offset of element j of block
+// b (R = 1: an index into the d^2 consecutive amplitudes of the plane).  Needs the same element-to-element stride in
+// every block; returns QSV_UNHANDLED otherwise.
+static int launch_plane(qsv_state *st, uint64_t d, uint64_t L, int nblocks, const int32_t *sizes,
+                        const std::vector<int64_t> &mat_start, const std::vector<int32_t> &idx_start,
+                        const std::vector<uint64_t> &off, const double *mats) {
+    const int plane = static_cast<int>(d * d);
+    int64_t stride = 0;
+    for (int b = 0; b < nblocks; ++b)
+        for (int j = 1; j < sizes[b]; ++j) {
+            const int64_t step = static_cast<int64_t>(off[idx_start[b] + j]) - static_cast<int64_t>(off[idx_start[b] + j - 1]);
+            if (stride == 0) stride = step;
+            if (step != stride) return QSV_UNHANDLED;
+        }
+    // every plane element: (block, row inside the block); elements outside all blocks are 1 x 1 identities
+    struct Elem { int e, block, row, size; };
+    std::vector<Elem> elems;
+    std::vector<uint8_t> covered(plane, 0);
+    for (int b = 0; b < nblocks; ++b)
+        for (int j = 0; j < sizes[b]; ++j) {
+            const int e = static_cast<int>(off[idx_start[b] + j]);
+            elems.push_back({e, b, j, sizes[b]});
+            covered[e] = 1;
+        }
+    for (int e = 0; e < plane; ++e)
+        if (!covered[e]) elems.push_back({e, -1, 0, 1});
+    std::stable_sort(elems.begin(), elems.end(), [](const Elem &x, const Elem &y) { return x.size > y.size; });
+    const int per_batch = PLANE_THREADS / plane;             // planes per batch
+    if (L % per_batch != 0) return QSV_UNHANDLED;
+    const int used = per_batch * plane;
+    // thread t: sorted position t / per_batch of plane slot t % per_batch, so that a wave holds elements of equal rank
+    std::vector<double> coef(static_cast<size_t>(PLANE_THREADS) * MAX_BLOCK, 0.0);
+    std::vector<int32_t> rd0(PLANE_THREADS, 0), wr(PLANE_THREADS, 0), trip(PLANE_THREADS / 64, 0);
+    for (int t = 0; t < used; ++t) {
+        const Elem &el = elems[t / per_batch];
+        const int slot = t % per_batch;
+        wr[t] = slot * plane + el.e;
+        if (el.block < 0) {
+            coef[static_cast<size_t>(t) * MAX_BLOCK] = 1.0;
+            rd0[t] = wr[t];
+        } else {
+            const double *row = mats + 2 * (mat_start[el.block] + static_cast<int64_t>(el.row) * el.size);
+            for (int k = 0; k < el.size; ++k) coef[static_cast<size_t>(t) * MAX_BLOCK + k] = row[2 * k];
+            rd0[t] = slot * plane + static_cast<int>(off[idx_start[el.block]]);
+        }
+        trip[t / 64] = std::max(trip[t / 64], el.size);
+    }
+    auto pad16 = [](size_t x) { return (x + 15) / 16 * 16; };
+    const size_t b_c = pad16(sizeof(double) * coef.size()), b_i = pad16(sizeof(int32_t) * PLANE_THREADS);
+    int rc = qsvk_ensure_matrix(st, b_c + 3 * b_i);
+    if (rc) return rc;
+    char *p = reinterpret_cast<char *>(st->dev_matrix);
+    double *d_c = reinterpret_cast<double *>(p);
+    int32_t *d_r = reinterpret_cast<int32_t *>(p + b_c), *d_w = reinterpret_cast<int32_t *>(p + b_c + b_i),
+            *d_t = reinterpret_cast<int32_t *>(p + b_c + 2 * b_i);
+    QSV_HIP(hipMemcpyAsync(d_c, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipMemcpyAsync(d_r, rd0.data(), sizeof(int32_t) * PLANE_THREADS, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipMemcpyAsync(d_w, wr.data(), sizeof(int32_t) * PLANE_THREADS, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipMemcpyAsync(d_t, trip.data(), sizeof(int32_t) * trip.size(), hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));  // all sources are pageable host memory that dies at return
+    PlaneArgs g;
+    g.batches = L / per_batch;
+    g.batch_amps = static_cast<uint32_t>(used);
+    g.stride = static_cast<int32_t>(stride);
+    int cus = 256;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st->device);
+    const unsigned grid = static_cast<unsigned>(std::min<uint64_t>(g.batches, static_cast<uint64_t>(cus)));
+    const bool nt = st->nontemporal != 0;
+    const int cstride = (stride == 31 || stride == -31) ? static_cast<int>(stride) : 0;
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_mode2_plane<%d, %s>", cstride, nt ? "true" : "false");
+#define QSV_LAUNCH_PLANE(S, N) \
+    hipLaunchKernelGGL((k_mode2_plane<S, N>), dim3(grid), dim3(PLANE_THREADS), 0, st->stream, st->data, g, d_c, d_r, d_w, d_t)
+    if (cstride == 31) { if (nt) QSV_LAUNCH_PLANE(31, true); else QSV_LAUNCH_PLANE(31, false); }
+    else if (cstride == -31) { if (nt) QSV_LAUNCH_PLANE(-31, true); else QSV_LAUNCH_PLANE(-31, false); }
+    else { if (nt) QSV_LAUNCH_PLANE(0, true); else QSV_LAUNCH_PLANE(0, false); }
+#undef QSV_LAUNCH_PLANE
+    return check_launch();
+}
+
 int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const int32_t *sizes,
                       const int32_t *plane_indices, const double *mats) {
     const uint64_t d = st->d;
@@ -466,6 +641,17 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
             return qsv_fail(QSV_EINVAL, "plane indices must be distinct and inside the (d, d) plane");
         off[i] = (pi / d) * stride0 + (pi % d) * stride1;
     }
+    bool real = true;
+    for (int64_t i = 0; i < mtot && real; ++i) real = mats[2 * i + 1] == 0.0;
+    if (real && R == 1 && Mid == 1 && d * d <= static_cast<uint64_t>(PLANE_THREADS) && st->plane_kernel) {
+        const int rc_plane = launch_plane(st, d, L, nblocks, sizes, mat_start, idx_start, off, mats);
+        if (rc_plane != QSV_UNHANDLED) return rc_plane;
+    }
+    std::vector<double> real_mats;
+    if (real) {  // one double per entry
+        real_mats.resize(mtot);
+        for (int64_t i = 0; i < mtot; ++i) real_mats[i] = mats[2 * i];
+    }
     // one device buffer: [mats | plane_off | mat_start | sizes | idx_start], every section 16-byte aligned
     auto pad16 = [](size_t x) { return (x + 15) / 16 * 16; };
     const size_t b_m = pad16(sizeof(double) * 2 * mtot), b_o = pad16(sizeof(uint64_t) * off.size()),
@@ -478,7 +664,8 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
     int64_t *d_s = reinterpret_cast<int64_t *>(p + b_m + b_o);
     int32_t *d_z = reinterpret_cast<int32_t *>(p + b_m + b_o + b_s);
     int32_t *d_i = reinterpret_cast<int32_t *>(p + b_m + b_o + b_s + b_z);
-    QSV_HIP(hipMemcpyAsync(d_m, mats, sizeof(double) * 2 * mtot, hipMemcpyHostToDevice, st->stream));
+    if (real) QSV_HIP(hipMemcpyAsync(d_m, real_mats.data(), sizeof(double) * mtot, hipMemcpyHostToDevice, st->stream));
+    else QSV_HIP(hipMemcpyAsync(d_m, mats, sizeof(double) * 2 * mtot, hipMemcpyHostToDevice, st->stream));
     QSV_HIP(hipMemcpyAsync(d_o, off.data(), sizeof(uint64_t) * off.size(), hipMemcpyHostToDevice, st->stream));
     QSV_HIP(hipMemcpyAsync(d_s, mat_start.data(), sizeof(int64_t) * nblocks, hipMemcpyHostToDevice, st->stream));
     QSV_HIP(hipMemcpyAsync(d_z, sizes, sizeof(int32_t) * nblocks, hipMemcpyHostToDevice, st->stream));
@@ -492,12 +679,22 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
     const uint64_t groups = (planes + threads - 1) / threads;
     const uint64_t items = (groups + 7) / 8 * 8 * nblocks;
     const unsigned grid = static_cast<unsigned>(items < 0x00ffffffull ? items : 0x00ffffffull);
-    if (threads == QSV_BLOCK)
-        hipLaunchKernelGGL(k_mode2_blocks<QSV_BLOCK>, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, L,
-                           static_cast<int>(d), Mid, R, nblocks, groups, d_z, d_s, d_i, d_o, d_m);
-    else
-        hipLaunchKernelGGL(k_mode2_blocks<64>, dim3(grid), dim3(64), 0, st->stream, st->data, L, static_cast<int>(d),
-                           Mid, R, nblocks, groups, d_z, d_s, d_i, d_o, d_m);
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_mode2_blocks<%d, %s>", threads, real ? "true" : "false");
+    if (threads == QSV_BLOCK) {
+        if (real)
+            hipLaunchKernelGGL((k_mode2_blocks<QSV_BLOCK, true>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, L,
+                               static_cast<int>(d), Mid, R, nblocks, groups, d_z, d_s, d_i, d_o, d_m);
+        else
+            hipLaunchKernelGGL((k_mode2_blocks<QSV_BLOCK, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, L,
+                               static_cast<int>(d), Mid, R, nblocks, groups, d_z, d_s, d_i, d_o, d_m);
+    } else {
+        if (real)
+            hipLaunchKernelGGL((k_mode2_blocks<64, true>), dim3(grid), dim3(64), 0, st->stream, st->data, L,
+                               static_cast<int>(d), Mid, R, nblocks, groups, d_z, d_s, d_i, d_o, d_m);
+        else
+            hipLaunchKernelGGL((k_mode2_blocks<64, false>), dim3(grid), dim3(64), 0, st->stream, st->data, L,
+                               static_cast<int>(d), Mid, R, nblocks, groups, d_z, d_s, d_i, d_o, d_m);
+    }
     return check_launch();
 }
 

@@ -431,6 +431,14 @@ class QuditState:
         _lib.call("qsv_timer_stop", self._h, C.byref(ms))
         return ms.value
 
+    def set_option(self, option: int, value: int) -> None:
+        _lib.call("qsv_set_option", self._h, int(option), int(value))
+
+    def last_kernel(self) -> str:
+        buf = C.create_string_buffer(128)
+        _lib.call("qsv_last_kernel", self._h, buf, 128)
+        return buf.value.decode()
+
 
 def tensor_apply_axis(dev_in: int, dev_out: int, L: int, d_in: int, d_out: int, R: int, matrix, device: int = 0,
                       stream: int = 0) -> None:

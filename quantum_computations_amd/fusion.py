@@ -83,9 +83,10 @@ def fuse_circuit(circuit: list, max_qubits: int = 4, n_qubits: int | None = None
     far -- the block can run without an exchange, the gate cannot, and merging would make the whole block wait for
     the qubit to be brought in.
 
-    ``n_qubits`` (the register size) makes the scheduler cost-aware: a 5-qubit block whose qubits include more than one
-    of the six least significant ones runs on the transposed variants of ``k_dense_big<5>`` at one wave per SIMD
-    (2.1-3.8 TB/s instead of ~5), so such unions are capped at 4 qubits (1.5-1.7 ms whatever the placement)."""
+    ``n_qubits`` is accepted for compatibility and unused: round 1 capped 5-qubit unions that contained more than one
+    of the six least significant qubits (the shuffle form of ``k_dense_big<5>`` ran them at 2.1-3.8 TB/s); the
+    line-granular kernel ``k_dense_lds`` runs 5-qubit blocks at 4.9-5.2 TB/s wherever their qubits sit, so the only
+    limit left is the block size."""
     if max_qubits < 2:
         return list(circuit)
     out: list = []
@@ -101,11 +102,7 @@ def fuse_circuit(circuit: list, max_qubits: int = 4, n_qubits: int | None = None
         mixed_now = {q for q in gate.indices if q in remote and not _conserves(gate, q)}
         if mixed_now & conserved & seen:
             return False             # the new gate mixes a rank bit the block only conserved so far
-        size = len(union) - len(conserved - mixed_now)
-        if size <= min(max_qubits, 4) or n_qubits is None:
-            return size <= max_qubits
-        low = sum(1 for q in union if n_qubits - 1 - q < 6)      # qubits that are lane bits of the kernels
-        return size <= max_qubits and low <= 1
+        return len(union) - len(conserved - mixed_now) <= max_qubits
 
     def flush(blocks):
         for b in blocks:

@@ -210,8 +210,9 @@ def test_fock_path_cfg4_small():
     assert abs(st.norm() - np.linalg.norm(want)) < 1e-12
 
 
+@pytest.mark.parametrize("plane_kernel", [1, 0])
 @pytest.mark.parametrize("n_modes", [3, 4])
-def test_fock_path_cfg4_at_cutoff_32(n_modes):
+def test_fock_path_cfg4_at_cutoff_32(n_modes, plane_kernel):
     """BASELINE config 4 at its own cutoff d = 32 (3 and 4 of its 6 modes: 32 Ki / 1 Mi amplitudes), on a random
     register.  d = 32 makes the register a 5-bit-per-mode qubit register, so this runs the instantiations the
     6-mode configuration launches: S through ``k_dense_big<5, KL>`` with KL = 5 (last mode: all target bits inside a
@@ -222,8 +223,10 @@ def test_fock_path_cfg4_at_cutoff_32(n_modes):
     rng = np.random.default_rng(320 + n_modes)
     psi = rng.standard_normal((d,) * n_modes) + 1j * rng.standard_normal((d,) * n_modes)
     psi /= np.linalg.norm(psi)
+    from quantum_computations_amd import _lib
     st = fock.FockState(n_modes, d)
     st.reg.upload(psi)
+    st.reg.set_option(_lib.OPT_PLANE_KERNEL, plane_kernel)   # last pair: workgroup-per-plane (1) / thread-per-plane (0)
     want = psi
     bs = fock.beamsplitter_matrix(d, np.pi / 4)
     for mode in range(n_modes):
@@ -236,6 +239,8 @@ def test_fock_path_cfg4_at_cutoff_32(n_modes):
         fock.BS(*pair, np.pi / 4).apply(st)
         want = CO.apply_two_axes(want, bs, *pair)
         assert maxdiff(st.contract(), want) < 1e-12, pair
+        if max(pair) == n_modes - 1:
+            assert st.reg.last_kernel().startswith("k_mode2_plane<" if plane_kernel else "k_mode2_blocks<64, true>")
     # a beam splitter with a phase has complex blocks (the real-matrix fast paths must not be taken for it)
     bs_c = fock.beamsplitter_blocks(d, 0.4, 0.9)
     st.reg.apply_two_mode_blocks(bs_c, n_modes - 2, n_modes - 1)
@@ -246,3 +251,37 @@ def test_fock_path_cfg4_at_cutoff_32(n_modes):
     want = CO.apply_axis(want, fock.squeeze_matrix(d, 0.3, 0.7), n_modes - 1)
     assert maxdiff(st.contract(), want) < 1e-12
     assert abs(st.norm() - np.linalg.norm(want)) < 1e-12
+
+
+@pytest.mark.parametrize("n_modes,d", [(4, 8), (5, 4), (3, 16), (3, 12)])
+def test_block_operator_on_the_last_two_modes(n_modes, d):
+    """``qsv_apply_mode2_blocks`` on the last pair (R = 1) at cutoffs where one workgroup of ``k_mode2_plane`` holds
+    several planes (d = 8: 16 planes, d = 4: 64, d = 16: 4; d = 12 does not divide and takes the general kernel), with
+    only some of the blocks given (the other plane elements must stay untouched), legs in either order, and a block set
+    whose elements are not equally spaced (general kernel again)."""
+    rng = np.random.default_rng(d * 10 + n_modes)
+    psi = rng.standard_normal((d,) * n_modes) + 1j * rng.standard_normal((d,) * n_modes)
+    st = QuditState.from_numpy(psi)
+    want = psi
+    a, b = n_modes - 2, n_modes - 1
+    full = fock.beamsplitter_blocks(d, 0.7)
+    kernels = []
+    for blocks, legs in [(full, (a, b)), (full, (b, a)), (full[2:d], (a, b)), (full[d - 1:], (b, a))]:
+        st.apply_two_mode_blocks(blocks, *legs)
+        kernels.append(st.last_kernel())
+        m = np.identity(d * d, dtype=complex)
+        for idx, block in blocks:
+            m[np.ix_(idx, idx)] = block
+        want = CO.apply_two_axes(want, m, *legs)
+        assert maxdiff(st.to_numpy(), want) < 1e-12, (legs, len(blocks))
+    expect = "k_mode2_plane<" if d != 12 else "k_mode2_blocks<64, true>"
+    assert all(k.startswith(expect) for k in kernels), kernels
+    # unequal spacing inside a block: not the plane kernel's case
+    idx = [0, 1, d + 2, 2 * d + 1][: min(4, d)]
+    q = np.linalg.qr(rng.standard_normal((len(idx), len(idx))))[0]
+    st.apply_two_mode_blocks([(idx, q)], a, b)
+    assert st.last_kernel().startswith("k_mode2_blocks<64")
+    m = np.identity(d * d, dtype=complex)
+    m[np.ix_(idx, idx)] = q
+    want = CO.apply_two_axes(want, m, a, b)
+    assert maxdiff(st.to_numpy(), want) < 1e-12

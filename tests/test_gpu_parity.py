@@ -246,28 +246,48 @@ def test_generic_kq(n, k):
     assert maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("k", [3, 4, 5])
-def test_register_blocked_kq_every_low_target_count(k):
-    """k_dense_big: 0..k of the targets among the six lane bits (the wave-transpose stages), legs in any order."""
+def test_register_blocked_kq_every_low_target_set(k, variant):
+    """k = 3..5 dense gates with EVERY set of target bits below 6 (all subsets of the six lane bits, up to k of them),
+    the other legs on random high bits, legs in any order, complex and real matrices.  ``variant`` 3 is the
+    line-granular kernel (k_dense_lds: address arithmetic for lane bits 3..5, LDS for bits 0..2), 1 the wave-shuffle
+    form (k_dense_big<K, KL>), 2 the no-exchange form, 0 the shipped per-case choice between them: all must agree
+    with the oracle."""
+    import itertools
+
+    from quantum_computations_amd import _lib
     n = k + 8
     rng = np.random.default_rng(50 + k)
     ket = W.random_ket(n, 31)
     dev = DeviceState.from_numpy(ket)
+    dev.set_option(_lib.OPT_KQ_VARIANT, variant)
     want = ket
     kernels = set()
     for n_low in range(k + 1):
-        for trial in range(2):
-            low_bits = [int(b) for b in rng.choice(6, size=n_low, replace=False)]
+        for low_bits in itertools.combinations(range(6), n_low):
             high_bits = [int(b) for b in rng.choice(np.arange(6, n), size=k - n_low, replace=False)]
-            bits = low_bits + high_bits
+            bits = list(low_bits) + high_bits
             rng.shuffle(bits)
             qs = [n - 1 - b for b in bits]
             u = W.haar_unitary(1 << k, rng)
+            if len(kernels) % 3 == 2:
+                u = np.linalg.qr(rng.standard_normal((1 << k, 1 << k)))[0]      # real: the two-FMA variant
             dev.apply_matrix(u, qs)
             kernels.add(dev.last_kernel())
             want = O.apply_gate(want, u, qs)
             assert maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL, (bits, dev.last_kernel())
-    assert len(kernels) == k + 1, kernels          # every KL instantiation was exercised
+    if variant == 0:
+        assert any(name.startswith("k_dense_lds<5") for name in kernels) == (k == 5), kernels
+    elif variant == 3:
+        assert all(name.startswith(f"k_dense_lds<{k}, ") for name in kernels), kernels
+        assert {name.split(", ")[1] for name in kernels} == {"0", "1", "2", "3"}     # 0..3 targets inside a line
+        assert {name.split(", ")[3] for name in kernels} == {"true>", "false>"}      # real and complex matrices
+    elif variant == 1:
+        assert {name.split(", ")[1] for name in kernels} == {str(j) for j in range(k + 1)}, kernels
+    else:
+        assert kernels == {f"k_dense_big<{k}, 0, false>"} or kernels == {f"k_dense_big<{k}, 0, true>",
+                                                                        f"k_dense_big<{k}, 0, false>"}, kernels
 
 
 @pytest.mark.parametrize("n", [1, 4, 9, 12])

@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--fetch", type=Path)
     ap.add_argument("--write", type=Path)
     ap.add_argument("--command", default="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
+    ap.add_argument("--name", default="pmc_traffic", help="profiles/rNN_<name>.md (pmc_traffic.json only for the default)")
+    ap.add_argument("--alg-bytes", type=float, default=0.0, help="algorithmic bytes per launch, for a ratio column")
     args = ap.parse_args()
     out = REPO / "profiles"
     out.mkdir(exist_ok=True)
@@ -71,8 +73,9 @@ def main():
                  f"Command (each pass): `rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- {args.command}`",
                  "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as read; both KiB -> bytes.",
                  "",
-                 "| kernel | launches | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes / launch | GiB |",
-                 "|---|---|---|---|---|---|"]
+                 "| kernel | launches | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes / launch | GiB | read GiB | written GiB"
+                 + (" | read / algorithmic | written / algorithmic |" if args.alg_bytes else " |"),
+                 "|---|---|---|---|---|---|---|---|" + ("---|---|" if args.alg_bytes else "")]
         for k in sorted(set(fetch) & set(write)):
             f, nf = fetch[k]
             w, _ = write[k]
@@ -80,10 +83,15 @@ def main():
             table[k] = {"hbm_bytes_per_launch": hbm, "fetch_kib_raw": f, "write_kib": w, "launches": nf,
                         "source": f"profiles/{tag}_pmc_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                   "separate passes, FETCH_SIZE x2)"}
-            lines.append(f"| `{k}` | {nf} | {f:.1f} | {w:.1f} | {hbm:.4g} | {hbm / 2**30:.3f} |")
-        (out / f"{tag}_pmc_traffic.md").write_text("\n".join(lines) + "\n")
-        (out / "pmc_traffic.json").write_text(json.dumps(table, indent=1, sort_keys=True) + "\n")
-        print(f"wrote {out / (tag + '_pmc_traffic.md')} and pmc_traffic.json")
+            row = (f"| `{k}` | {nf} | {f:.1f} | {w:.1f} | {hbm:.4g} | {hbm / 2**30:.3f} | {2 * f / 2**20:.3f} | "
+                   f"{w / 2**20:.3f} |")
+            if args.alg_bytes:
+                row += f" {2 * f * 1024 / (args.alg_bytes / 2):.3f} | {w * 1024 / (args.alg_bytes / 2):.3f} |"
+            lines.append(row)
+        (out / f"{tag}_{args.name}.md").write_text("\n".join(lines) + "\n")
+        if args.name == "pmc_traffic":
+            (out / "pmc_traffic.json").write_text(json.dumps(table, indent=1, sort_keys=True) + "\n")
+        print(f"wrote {out / (tag + '_' + args.name + '.md')}")
 
 
 if __name__ == "__main__":
