@@ -58,8 +58,11 @@ enum {
                                 the measured best per case, 1 = wave-shuffle butterflies, 2 = no exchange (per-thread
                                 strided access), 3 = line-granular exchange (address arithmetic for bits 3..5, LDS for
                                 bits 0..2).  Same results; for measurements */
-    QSV_OPT_PLANE_KERNEL = 8 /* qsv_apply_mode2_blocks on the last two modes with real blocks: 1 (default) = one
+    QSV_OPT_PLANE_KERNEL = 8, /* qsv_apply_mode2_blocks on the last two modes with real blocks: 1 (default) = one
                                 workgroup per (d x d) plane staged through LDS, 0 = one thread per plane */
+    QSV_OPT_READOUT_VARIANT = 9 /* qsv_measure_probs / collapse / insert / permute / k-qubit diagonals: 0 (default) =
+                                streaming kernels (whole 1 KiB segments per wave whatever the bit), 1 = plain
+                                grid-stride kernels (always used below 14 qubits).  Same results; for measurements */
 };
 
 typedef struct qsv_state qsv_state;
@@ -139,6 +142,16 @@ int qsv_inner(qsv_state *a, qsv_state *b, double *re, double *im);
 /* <psi| P |psi> for the Pauli string P = paulis[0] on qubits[0] (x) paulis[1] on qubits[1] ... ('I','X','Y','Z'):
  * npq.expect (numpy_quantum.py:194-201) for tensor products of npq.PAULIS without building the 2^N operator. */
 int qsv_expect_pauli(qsv_state *st, int k, const int *qubits, const char *paulis, double *re, double *im);
+/* Reduced density matrix of the k <= 6 qubits `qubits` (all others traced out) in one read pass over the register:
+ * rho[i][j] = sum_rest psi[i, rest] conj(psi[j, rest]), written row-major as 4^k complex numbers, qubits[0] the most
+ * significant bit of i and j.  What a caller of the reference gets from npq.ket2dm (numpy_quantum.py:110-113)
+ * followed by a partial trace -- without the 2^N x 2^N matrix. */
+int qsv_reduced_density(qsv_state *st, int k, const int *qubits, double *rho);
+/* <a| rho |a> for an n-qubit ket `ket` and a density matrix `rho` held row-major as a 2n-qubit register (the layout
+ * Gate.apply uses for U rho U^dagger): the ket / density-matrix branches of npq.fidelity (numpy_quantum.py:153-156).
+ * npq.purity (numpy_quantum.py:164-166) of such a register is qsv_norm2: tr(rho rho) = sum |rho_ij|^2 for a
+ * hermitian rho. */
+int qsv_expect_density(qsv_state *ket, qsv_state *rho, double *re, double *im);
 /* Draw `shots` computational-basis outcomes from |amp|^2 by inverse-CDF sampling: out[s] is the smallest basis
  * index whose cumulative probability exceeds u[s] * norm^2 (u[s] in [0, 1), drawn by the caller).  The register
  * is not collapsed.  Equivalent to measuring every qubit with MZ (gates.py:188-190) on independent copies. */

@@ -10,7 +10,7 @@ LIB_PATH = Path(os.environ.get("QSV_LIBRARY", PKG_DIR / "libqsv.so"))
 
 QSV_OK, QSV_EINVAL, QSV_ENOMEM, QSV_EHIP, QSV_ESTATE = 0, -1, -2, -3, -4
 OPT_SPECIALIZE, OPT_UNROLL, OPT_GRID_CAP, OPT_NONTEMPORAL, OPT_ITEM_STRIDE_BIT, OPT_TILE_REGIONS = 1, 2, 3, 4, 5, 6
-OPT_KQ_VARIANT, OPT_PLANE_KERNEL = 7, 8
+OPT_KQ_VARIANT, OPT_PLANE_KERNEL, OPT_READOUT_VARIANT = 7, 8, 9
 
 _state_p = C.c_void_p
 _dbl_p = C.POINTER(C.c_double)
@@ -54,6 +54,8 @@ SIGNATURES: dict[str, list] = {
     "qsv_probabilities": [_state_p, _u64_p, C.c_int, _dbl_p],
     "qsv_inner": [_state_p, _state_p, _dbl_p, _dbl_p],
     "qsv_expect_pauli": [_state_p, C.c_int, _int_p, C.c_char_p, _dbl_p, _dbl_p],
+    "qsv_reduced_density": [_state_p, C.c_int, _int_p, _dbl_p],
+    "qsv_expect_density": [_state_p, _state_p, _dbl_p, _dbl_p],
     "qsv_sample": [_state_p, C.c_int, C.c_void_p, C.c_void_p],
     "qsv_create_qudit": [C.c_int, C.c_int, C.c_int, C.POINTER(_state_p)],
     "qsv_create_qudit_view": [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(_state_p)],

@@ -249,6 +249,7 @@ int qsv_set_option(qsv_state *st, int option, int64_t value) {
             st->ubit = static_cast<int>(value);
             return QSV_OK;
         case QSV_OPT_PLANE_KERNEL: st->plane_kernel = value != 0; return QSV_OK;
+        case QSV_OPT_READOUT_VARIANT: st->readout_variant = value != 0; return QSV_OK;
         case QSV_OPT_KQ_VARIANT:
             if (value < 0 || value > 3) return qsv_fail(QSV_EINVAL, "k-qubit kernel variant must be 0, 1, 2 or 3");
             st->kq_variant = static_cast<int>(value);
@@ -607,6 +608,27 @@ int qsv_inner(qsv_state *a, qsv_state *b, double *re, double *im) {
     if (a->device != b->device) return qsv_fail(QSV_EINVAL, "registers on different devices");
     QSV_HIP(hipSetDevice(a->device));
     return qsvk_inner(a, b, re, im);
+}
+
+int qsv_reduced_density(qsv_state *st, int k, const int *qubits, double *rho) {
+    if (!valid(st) || !qubits || !rho) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (st->kind != 0) return qsv_fail(QSV_ESTATE, "this call needs a qubit register");
+    if (k < 1 || k > QSV_MAX_K) return qsv_fail(QSV_EINVAL, "keep between 1 and 6 qubits");
+    int rc = check_qubits(st, k, qubits);
+    if (rc) return rc;
+    QSV_HIP(hipSetDevice(st->device));
+    std::vector<int> bits(k);
+    for (int j = 0; j < k; ++j) bits[j] = bit_of(st, qubits[j]);
+    return qsvk_reduced_density(st, k, bits.data(), rho);
+}
+
+int qsv_expect_density(qsv_state *ket, qsv_state *rho, double *re, double *im) {
+    if (!valid(ket) || !valid(rho) || !re || !im) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (ket->kind != 0 || rho->kind != 0) return qsv_fail(QSV_ESTATE, "this call needs qubit registers");
+    if (rho->n != 2 * ket->n) return qsv_fail(QSV_EINVAL, "the density register must have twice the ket's qubits");
+    if (ket->device != rho->device) return qsv_fail(QSV_EINVAL, "registers on different devices");
+    QSV_HIP(hipSetDevice(rho->device));
+    return qsvk_expect_density(ket, rho, re, im);
 }
 
 // ---- d-level modes ----------------------------------------------------------------------------------

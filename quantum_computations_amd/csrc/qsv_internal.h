@@ -79,6 +79,8 @@ struct qsv_state {
     int remap = -1;                   // tile order: -1 = per-kernel default, 0 = plain, R = regions
     int kq_variant = 0;               // k = 3..5 gates: 0 = per-case choice, 1 = wave shuffles (k_dense_big<K, KL>),
                                       // 2 = no transpose (per-thread strided access), 3 = line-granular (k_dense_lds)
+    int readout_variant = 0;          // measurement / insertion / permutation / table diagonals: 0 = streaming forms,
+                                      // 1 = round-1 grid-stride forms
     int plane_kernel = 1;             // block-diagonal two-mode operators on the last two modes: 1 = workgroup-per-plane
                                       // form (k_mode2_plane), 0 = plane-per-thread form (k_mode2_blocks<64>)
     char last_kernel[96] = "";        // name of the most recent gate kernel launched (qsv_last_kernel)
@@ -109,6 +111,8 @@ int qsvk_norm2(qsv_state *st, double *out);
 int qsvk_inner(qsv_state *a, qsv_state *b, double *re, double *im);
 int qsvk_probabilities(qsv_state *st, const uint64_t *indices, int count, double *out);
 int qsvk_expect_pauli(qsv_state *st, uint64_t xmask, uint64_t zmask, int n_y, double *re, double *im);
+int qsvk_reduced_density(qsv_state *st, int k, const int *bits, double *rho_out);
+int qsvk_expect_density(qsv_state *ket, qsv_state *rho, double *re, double *im);
 int qsvk_sample(qsv_state *st, int shots, const double *u, uint64_t *out);
 int qsvk_fill_random(qsv_state *st, uint64_t seed, uint64_t index_offset, double *norm2);
 int qsvk_scale(qsv_state *st, double re, double im);

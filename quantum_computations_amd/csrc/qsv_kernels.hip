@@ -464,6 +464,80 @@ __global__ __launch_bounds__(BLOCK) void k_dense_lds(amp_t *__restrict__ a, cons
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------------
+// 6-qubit dense gates.  2^6 complex FMAs per amplitude are 16 flop/B: above the fp64 ridge of the chip (~10 flop/B),
+// so this one kernel of the gate path is bounded by arithmetic, not by HBM, and a 64 x 64 matrix times a (64 x groups)
+// panel is a GEMM: it runs on the f64 matrix cores (v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][j = lane & 15], D col = lane & 15, row = (lane >> 4) + 4 reg; same peak as the vector pipe, but 64
+// VGPRs of inputs per lane instead of 256, so two waves per SIMD overlap loads with arithmetic -- the register-blocked
+// vector form ran at 8.5 TFLOP/s, one wave per SIMD, stalled on its 1 KiB matrix rows).
+// A wave owns 16 consecutive groups (index bits 0..3 must not be targets; the launcher moves lower targets out of the
+// way with a qubit permutation before and after): lane (li, lk) holds amplitudes 4 s + lk, s = 0..15, of group li.
+// The matrix sits in LDS column-major (real and imaginary planes), a complex product is four real MFMAs, a real
+// matrix needs two.  Loads and stores are four 256-byte runs per wave-instruction: whole 128-byte lines.
+// ----------------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+struct Mfma6Args {
+    uint64_t W;          // groups = amps / 64
+    uint64_t or_mask;    // unused (0); lets deposit() serve this struct too
+    int32_t nins;        // 6
+    uint8_t pos[8];      // ascending target bits (all >= 4)
+};
+
+template <bool NT, bool REALM>
+__global__ __launch_bounds__(QSV_BLOCK) void k_dense6_mfma(amp_t *__restrict__ a, const Mfma6Args g,
+                                                           const double *__restrict__ Mcol,  // [plane][col][row]
+                                                           const uint64_t *__restrict__ hoff) {
+    extern __shared__ __attribute__((aligned(16))) char smem6[];
+    double *mre = reinterpret_cast<double *>(smem6);
+    double *mim = mre + 4096;
+    uint64_t *off = reinterpret_cast<uint64_t *>(mre + (REALM ? 4096 : 8192));
+    for (int i = threadIdx.x; i < (REALM ? 4096 : 8192); i += QSV_BLOCK) mre[i] = Mcol[i];
+    if (threadIdx.x < 64) off[threadIdx.x] = hoff[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const uint64_t wave = blockIdx.x * (QSV_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t waves = static_cast<uint64_t>(gridDim.x) * (QSV_BLOCK / 64);
+    for (uint64_t tile = wave; tile * 16 < g.W; tile += waves) {
+        const uint64_t base = deposit(tile * 16 + li, g);
+        amp_t x[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) x[s] = ld<NT>(a + base + off[4 * s + lk]);
+        f64x4 cre[4], cim[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cre[t] = cim[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            double are[4], aim[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                are[t] = mre[(4 * s + lk) * 64 + 16 * t + li];
+                if constexpr (!REALM) aim[t] = mim[(4 * s + lk) * 64 + 16 * t + li];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {  // dependent updates of one accumulator stay 8 instructions apart
+                cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[t], x[s].x, cre[t], 0, 0, 0);
+                cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[t], x[s].y, cim[t], 0, 0, 0);
+            }
+            if constexpr (!REALM) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aim[t], x[s].y, cre[t], 0, 0, 0);
+                    cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[t], x[s].x, cim[t], 0, 0, 0);
+                }
+            }
+        }
+        // in place: the wave has read every amplitude of its 16 groups before the first of these stores can issue
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                st<NT>(a + base + off[16 * t + lk + 4 * r], amp_t{cre[t][r], cim[t][r]});
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------
 // Reductions, measurement, insertion, permutation, fills.
 // ----------------------------------------------------------------------------------------------------
@@ -732,6 +806,340 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_fill_random(amp_t *__restrict__ a
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------------
+// Streaming forms of the read-out / reshaping kernels (registers of at least 2^14 amplitudes; the plain grid-stride
+// forms above stay for smaller ones).  Common shape: one work item = 64 consecutive amplitudes per wave-instruction,
+// ITEMS independent items per thread in flight, nontemporal accesses (every amplitude is touched once), and a target
+// bit below 6 is resolved inside the wave -- the partner amplitude comes from __shfl_xor, compaction / expansion by
+// one qubit is a lane gather -- so that every global access is a whole 1 KiB segment whatever the bit.
+// ----------------------------------------------------------------------------------------------------
+constexpr int RO_ITEMS = 4;
+constexpr int RO_MIN_QUBITS = 14;  // below this the plain grid-stride forms run (tiles of 2^10 amplitudes must divide)
+
+__device__ __forceinline__ amp_t shfl_amp(amp_t v, int src_lane) {
+    amp_t r;
+    r.x = __shfl(v.x, src_lane, 64);
+    r.y = __shfl(v.y, src_lane, 64);
+    return r;
+}
+
+// partials[2*block + s] = sum over this block's pairs of |eig_s[0] a0 + eig_s[1] a1|^2   (M.apply, gates.py:173-183)
+template <bool LOW>
+__global__ __launch_bounds__(QSV_BLOCK) void k_measure_probs_s(const amp_t *__restrict__ a, uint64_t amps, int bit,
+                                                               cplx e00, cplx e01, cplx e10, cplx e11,
+                                                               double *__restrict__ partials) {
+    double p0 = 0.0, p1 = 0.0;
+    const uint64_t s = 1ull << bit;
+    if constexpr (LOW) {
+        // natural order: a lane whose bit is 0 holds a0 and fetches a1 from its partner (and accumulates outcome 0),
+        // a lane whose bit is 1 holds a1, fetches a0 and accumulates outcome 1: no lane idles, no amplitude is read twice
+        const bool up = (threadIdx.x >> bit) & 1;
+        const cplx mine = up ? e11 : e00, theirs = up ? e10 : e01;
+        double acc = 0.0;
+        const uint64_t stride = static_cast<uint64_t>(gridDim.x) * QSV_BLOCK * RO_ITEMS;
+        for (uint64_t i0 = blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) * RO_ITEMS + threadIdx.x; i0 < amps; i0 += stride) {
+            amp_t v[RO_ITEMS];
+#pragma unroll
+            for (int u = 0; u < RO_ITEMS; ++u) v[u] = __builtin_nontemporal_load(a + i0 + u * QSV_BLOCK);
+#pragma unroll
+            for (int u = 0; u < RO_ITEMS; ++u) {
+                const amp_t r = cfma(theirs, shfl_xor_amp(v[u], 1 << bit), cmul(mine, v[u]));
+                acc += r.x * r.x + r.y * r.y;
+            }
+        }
+        p0 = up ? 0.0 : acc;
+        p1 = up ? acc : 0.0;
+    } else {
+        const uint64_t pairs = amps >> 1;
+        const uint64_t stride = static_cast<uint64_t>(gridDim.x) * QSV_BLOCK * RO_ITEMS;
+        for (uint64_t w0 = blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) * RO_ITEMS + threadIdx.x; w0 < pairs; w0 += stride) {
+            amp_t lo[RO_ITEMS], hi[RO_ITEMS];
+#pragma unroll
+            for (int u = 0; u < RO_ITEMS; ++u) {
+                const uint64_t i = insert_zero(w0 + u * QSV_BLOCK, bit);
+                lo[u] = __builtin_nontemporal_load(a + i);
+                hi[u] = __builtin_nontemporal_load(a + i + s);
+            }
+#pragma unroll
+            for (int u = 0; u < RO_ITEMS; ++u) {
+                const amp_t r0 = cfma(e01, hi[u], cmul(e00, lo[u]));
+                const amp_t r1 = cfma(e11, hi[u], cmul(e10, lo[u]));
+                p0 += r0.x * r0.x + r0.y * r0.y;
+                p1 += r1.x * r1.x + r1.y * r1.y;
+            }
+        }
+    }
+    block_sum2(p0, p1);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = p0;
+        partials[2 * blockIdx.x + 1] = p1;
+    }
+}
+
+// out[w] = scale * (e0 a[i0] + e1 a[i0 + s]), i0 = w with a zero inserted at `bit`.
+template <bool LOW>
+__global__ __launch_bounds__(QSV_BLOCK) void k_collapse_s(const amp_t *__restrict__ a, amp_t *__restrict__ out,
+                                                          uint64_t pairs, int bit, cplx e0, cplx e1, double scale) {
+    const cplx f0 = {e0.re * scale, e0.im * scale}, f1 = {e1.re * scale, e1.im * scale};
+    const uint64_t w0 = (blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + (threadIdx.x & ~63u)) * RO_ITEMS + (threadIdx.x & 63);
+    if constexpr (LOW) {
+        // a wave turns 2 * RO_ITEMS rows of 64 amplitudes into RO_ITEMS rows of 64 results: the pair sum lands in the
+        // lanes whose bit is 0, and output lane l gathers it from lane insert_zero(l & 31, bit) of row l >> 5
+        const int lane = threadIdx.x & 63;
+        const int src = static_cast<int>(insert_zero(static_cast<uint64_t>(lane & 31), bit));
+        amp_t v[2 * RO_ITEMS];
+#pragma unroll
+        for (int u = 0; u < 2 * RO_ITEMS; ++u) v[u] = __builtin_nontemporal_load(a + 2 * (w0 - lane) + u * 64 + lane);
+#pragma unroll
+        for (int u = 0; u < RO_ITEMS; ++u) {
+            const amp_t ra = cfma(f1, shfl_xor_amp(v[2 * u], 1 << bit), cmul(f0, v[2 * u]));
+            const amp_t rb = cfma(f1, shfl_xor_amp(v[2 * u + 1], 1 << bit), cmul(f0, v[2 * u + 1]));
+            const amp_t ga = shfl_amp(ra, src), gb = shfl_amp(rb, src);
+            __builtin_nontemporal_store(lane < 32 ? ga : gb, out + w0 + u * 64);
+        }
+    } else {
+        const uint64_t s = 1ull << bit;
+        amp_t lo[RO_ITEMS], hi[RO_ITEMS];
+#pragma unroll
+        for (int u = 0; u < RO_ITEMS; ++u) {
+            const uint64_t i = insert_zero(w0 + u * 64, bit);
+            lo[u] = __builtin_nontemporal_load(a + i);
+            hi[u] = __builtin_nontemporal_load(a + i + s);
+        }
+#pragma unroll
+        for (int u = 0; u < RO_ITEMS; ++u)
+            __builtin_nontemporal_store(cfma(f1, hi[u], cmul(f0, lo[u])), out + w0 + u * 64);
+    }
+}
+
+// out[j] = amp[bit(j)] * a[j with the bit removed]
+template <bool LOW>
+__global__ __launch_bounds__(QSV_BLOCK) void k_insert_s(const amp_t *__restrict__ a, amp_t *__restrict__ out,
+                                                        uint64_t in_amps, int bit, cplx c0, cplx c1) {
+    const uint64_t w0 = (blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + (threadIdx.x & ~63u)) * RO_ITEMS + (threadIdx.x & 63);
+    amp_t v[RO_ITEMS];
+#pragma unroll
+    for (int u = 0; u < RO_ITEMS; ++u) v[u] = __builtin_nontemporal_load(a + w0 + u * 64);
+    if constexpr (LOW) {
+        // a row of 64 inputs becomes two rows of 64 outputs: output lane l of row h reads input lane 32 h + (l without
+        // its `bit`) and takes the factor of its own bit
+        const int lane = threadIdx.x & 63;
+        const int from = static_cast<int>(((static_cast<uint32_t>(lane) >> (bit + 1)) << bit) | (lane & ((1 << bit) - 1)));
+        const cplx c = ((lane >> bit) & 1) ? c1 : c0;
+#pragma unroll
+        for (int u = 0; u < RO_ITEMS; ++u) {
+            const uint64_t o = 2 * (w0 - lane + u * 64) + lane;
+            __builtin_nontemporal_store(cmul(c, shfl_amp(v[u], from)), out + o);
+            __builtin_nontemporal_store(cmul(c, shfl_amp(v[u], 32 + from)), out + o + 64);
+        }
+    } else {
+        const uint64_t s = 1ull << bit;
+#pragma unroll
+        for (int u = 0; u < RO_ITEMS; ++u) {
+            const uint64_t o = insert_zero(w0 + u * 64, bit);
+            __builtin_nontemporal_store(cmul(c0, v[u]), out + o);
+            __builtin_nontemporal_store(cmul(c1, v[u]), out + o + s);
+        }
+    }
+}
+
+// Qubit permutation: out[j] = a[p(j)], p moves index bits.  A wave owns a tile of 64 amplitudes that is 8 whole
+// 128-byte lines on BOTH sides: the tile's six index bits are the destination bits 0..2 (inside a line), the destination
+// bits fed by source bits 0..2, and filler bits.  Stores are consecutive within each line; loads hit 8 whole source lines
+// in some lane order -- no LDS and no shuffle, the coalescer sees complete lines either way.  The tile's base addresses
+// are wave-uniform: the destination base is the tile number with zeros inserted at the tile's bit positions, the source
+// base is that number pushed through the bit permutation one byte at a time (256-entry tables, scalar loads).
+struct PermTileArgs {
+    uint64_t tiles;          // amps / 64
+    int32_t bytes;           // ceil(n / 8): lookup tables
+    uint8_t tile_dst[6];     // destination bit of lane bit k, ascending (tile_dst[0..2] = 0, 1, 2)
+    uint8_t tile_src[6];     // source bit that feeds it
+};
+
+__global__ __launch_bounds__(QSV_BLOCK) void k_permute_s(const amp_t *__restrict__ a, amp_t *__restrict__ out,
+                                                         const PermTileArgs g,
+                                                         const uint64_t *__restrict__ lut /*[bytes][256]*/) {
+    const int lane = threadIdx.x & 63;
+    uint64_t dst_lane = 0, src_lane = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint64_t b = (lane >> k) & 1;
+        dst_lane |= b << g.tile_dst[k];
+        src_lane |= b << g.tile_src[k];
+    }
+    // wave-uniform on purpose (readfirstlane): the per-tile address arithmetic below then runs on the scalar unit
+    const uint64_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (QSV_BLOCK / 64) + (threadIdx.x >> 6));
+    const uint64_t waves = static_cast<uint64_t>(gridDim.x) * (QSV_BLOCK / 64);
+    for (uint64_t t0 = wave * RO_ITEMS; t0 < g.tiles; t0 += waves * RO_ITEMS) {
+        amp_t v[RO_ITEMS];
+        uint64_t dst[RO_ITEMS];
+#pragma unroll
+        for (int u = 0; u < RO_ITEMS; ++u) {
+            uint64_t d = t0 + u;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d = insert_zero(d, g.tile_dst[k]);
+            uint64_t sidx = 0;
+            for (int b = 0; b < g.bytes; ++b) sidx |= lut[b * 256 + ((d >> (8 * b)) & 255)];
+            dst[u] = d | dst_lane;
+            v[u] = amp_t{0.0, 0.0};
+            if (t0 + u < g.tiles) v[u] = __builtin_nontemporal_load(a + (sidx | src_lane));
+        }
+#pragma unroll
+        for (int u = 0; u < RO_ITEMS; ++u)
+            if (t0 + u < g.tiles) __builtin_nontemporal_store(v[u], out + dst[u]);
+    }
+}
+
+// K-qubit diagonal (K <= 6): a[i] *= table[bits of i at bitpos], natural order, table in LDS.
+__global__ __launch_bounds__(QSV_BLOCK) void k_diag_table_s(amp_t *__restrict__ a, uint64_t amps, int K,
+                                                           const uint8_t *__restrict__ bitpos,
+                                                           const double *__restrict__ table) {
+    __shared__ amp_t tab[1 << QSV_MAX_K];
+    __shared__ int bp[QSV_MAX_K];
+    if (threadIdx.x < (1 << K)) tab[threadIdx.x] = amp_t{table[2 * threadIdx.x], table[2 * threadIdx.x + 1]};
+    if (threadIdx.x < K) bp[threadIdx.x] = bitpos[threadIdx.x];
+    __syncthreads();
+    const uint64_t i0 = blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) * RO_ITEMS + threadIdx.x;
+    amp_t v[RO_ITEMS];
+#pragma unroll
+    for (int u = 0; u < RO_ITEMS; ++u) v[u] = __builtin_nontemporal_load(a + i0 + u * QSV_BLOCK);
+#pragma unroll
+    for (int u = 0; u < RO_ITEMS; ++u) {
+        const uint64_t i = i0 + u * QSV_BLOCK;
+        int sel = 0;
+        for (int j = 0; j < K; ++j) sel |= static_cast<int>((i >> bp[j]) & 1ull) << (K - 1 - j);
+        const amp_t d = tab[sel];
+        __builtin_nontemporal_store(cmul(cplx{d.x, d.y}, v[u]), a + i);
+    }
+}
+
+
+// ----------------------------------------------------------------------------------------------------
+// Reduced density matrix of k <= 6 kept qubits in ONE read pass:  rho[i][j] = sum_g psi[i, g] conj(psi[j, g]),
+// g running over the 2^(n-k) settings of the other qubits.  That is X X^H for the (2^k x 2^(n-k)) matrix X -- a rank
+// update with a tiny result -- and runs on the f64 matrix cores: a lane (i = lane & 15, kk = lane >> 4) loads ONE
+// amplitude, row i of group 4 q + kk, and the same register pair serves as A[i][kk] and as B[kk][j] of
+// v_mfma_f64_16x16x4_f64 (re = xr xr^T + xi xi^T, im = xi xr^T - xr xi^T).  T = 1, 2, 4 row tiles of 16 cover
+// 2^k <= 16, 32, 64; only the upper triangle of tiles is accumulated (rho is Hermitian).  The sum is deterministic:
+// waves add into their workgroup's LDS tile one after the other, workgroups write partials, a second launch adds
+// the partials in index order.
+// ----------------------------------------------------------------------------------------------------
+struct RdmArgs {
+    uint64_t W;          // groups = amps >> k
+    uint64_t or_mask;    // unused (0); lets deposit() serve this struct too
+    int32_t nins;        // k
+    int32_t D;           // 2^k
+    uint8_t pos[8];      // ascending kept bits
+};
+
+template <int T>
+__global__ __launch_bounds__(QSV_BLOCK) void k_rdm(const amp_t *__restrict__ a, const RdmArgs g,
+                                                   const uint64_t *__restrict__ hoff,  // [16 T] row offsets
+                                                   double *__restrict__ partials) {    // [grid][P][2][256]
+    constexpr int P = T * (T + 1) / 2;
+    __shared__ double red[P * 2 * 256];
+    const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+    uint64_t row_off[T];
+    bool row_ok[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        row_ok[t] = 16 * t + i < g.D;
+        row_off[t] = row_ok[t] ? hoff[16 * t + i] : 0;
+    }
+    f64x4 re[P], im[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) re[p] = im[p] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const uint64_t quads = g.W >> 2;
+    const uint64_t wave = blockIdx.x * (QSV_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint64_t waves = static_cast<uint64_t>(gridDim.x) * (QSV_BLOCK / 64);
+    for (uint64_t q = wave; q < quads; q += waves) {
+        const uint64_t base = deposit(4 * q + kk, g);
+        amp_t x[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            x[t] = amp_t{0.0, 0.0};
+            if (row_ok[t]) x[t] = __builtin_nontemporal_load(a + base + row_off[t]);
+        }
+        int p = 0;
+#pragma unroll
+        for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+            for (int tj = ti; tj < T; ++tj, ++p) {
+                re[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti].x, x[tj].x, re[p], 0, 0, 0);
+                im[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti].y, x[tj].x, im[p], 0, 0, 0);
+                re[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti].y, x[tj].y, re[p], 0, 0, 0);
+                im[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[ti].x, x[tj].y, im[p], 0, 0, 0);
+            }
+    }
+    // deterministic sum over the four waves of the workgroup, then one partial per workgroup
+    for (int wv = 0; wv < QSV_BLOCK / 64; ++wv) {
+        if ((threadIdx.x >> 6) == wv) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double *slot_re = red + ((p * 2 + 0) * 4 + r) * 64 + lane;
+                    double *slot_im = red + ((p * 2 + 1) * 4 + r) * 64 + lane;
+                    *slot_re = (wv == 0 ? 0.0 : *slot_re) + re[p][r];
+                    *slot_im = (wv == 0 ? 0.0 : *slot_im) + im[p][r];
+                }
+        }
+        __syncthreads();
+    }
+    double *out = partials + static_cast<size_t>(blockIdx.x) * (P * 2 * 256);
+    for (int e = threadIdx.x; e < P * 2 * 256; e += QSV_BLOCK) out[e] = red[e];
+}
+
+// out[e] = sum over blocks (in index order) of partials[block][e]
+__global__ __launch_bounds__(QSV_BLOCK) void k_sum_partials(const double *__restrict__ partials, int blocks, int entries,
+                                                            double *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= entries) return;
+    double s = 0.0;
+    for (int b = 0; b < blocks; ++b) s += partials[static_cast<size_t>(b) * entries + e];
+    out[e] = s;
+}
+
+// Small registers: one thread per entry (i, j) of rho walks every group (2^n amplitudes < 2^14: microseconds).
+__global__ __launch_bounds__(QSV_BLOCK) void k_rdm_small(const amp_t *__restrict__ a, const RdmArgs g,
+                                                         const uint64_t *__restrict__ hoff, double *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= g.D * g.D) return;
+    const int i = e / g.D, j = e % g.D;
+    double sr = 0.0, si = 0.0;
+    for (uint64_t w = 0; w < g.W; ++w) {
+        const uint64_t base = deposit(w, g);
+        const amp_t x = a[base + hoff[i]], y = a[base + hoff[j]];
+        sr += x.x * y.x + x.y * y.y;   // x conj(y)
+        si += x.y * y.x - x.x * y.y;
+    }
+    out[2 * e] = sr;
+    out[2 * e + 1] = si;
+}
+
+// <a| rho |a> for a ket `a` (2^n amplitudes) and a density matrix stored row-major as a 2n-qubit register:
+// partials[2b], [2b+1] = this block's share of sum_ij conj(a_i) rho_ij a_j.  rho is streamed once; the ket stays in L2.
+__global__ __launch_bounds__(QSV_BLOCK) void k_expect_density(const amp_t *__restrict__ ket, const amp_t *__restrict__ rho,
+                                                              uint64_t dim_bits, double *__restrict__ partials) {
+    double re = 0.0, im = 0.0;
+    const uint64_t total = 1ull << (2 * dim_bits), mask = (1ull << dim_bits) - 1;
+    for (uint64_t e = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const amp_t r = __builtin_nontemporal_load(rho + e);
+        const amp_t ai = ket[e >> dim_bits], aj = ket[e & mask];
+        // conj(ai) * aj
+        const double cr = ai.x * aj.x + ai.y * aj.y, ci = ai.x * aj.y - ai.y * aj.x;
+        re += cr * r.x - ci * r.y;
+        im += cr * r.y + ci * r.x;
+    }
+    block_sum2(re, im);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = re;
+        partials[2 * blockIdx.x + 1] = im;
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------
 // host-side helpers
 // ----------------------------------------------------------------------------------------------------
@@ -991,6 +1399,8 @@ static int dispatch_big(qsv_state *st, int KL, bool nt, dim3 gd, const BigArgs &
 }
 
 
+constexpr int QSV_UNHANDLED_KQ = 1 << 20;  // internal: "not this kernel's case, take the gather kernel"
+
 template <int K, int KB, int BLOCK>
 static void launch_lds_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const LdsArgs &g, const uint64_t *dev_off) {
     const dim3 bd(BLOCK);
@@ -1040,7 +1450,9 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     // the same kernel's two-FMA arithmetic (5.4-5.8 TB/s); k = 3, 4 and k = 5 on high bits -> the shuffle form
     // (its butterflies are cheap up to 16 amplitudes per thread: 5.6-6.0 TB/s).  QSV_OPT_KQ_VARIANT overrides.
     const bool fits = (st->amps >> k) >= 64 && (st->amps >> k) % 64 == 0;
-    const bool use_lds = fits && (st->kq_variant == 3 || (st->kq_variant == 0 && k == 5 && (KL > 0 || real_matrix)));
+    const bool use_lds = fits && (k == 6 || st->kq_variant == 3 ||
+                                  (st->kq_variant == 0 && k == 5 && (KL > 0 || real_matrix)));
+    if (k == 6 && !use_lds) return QSV_UNHANDLED_KQ;  // only the line-granular kernel is built for 64 x 64 matrices
     int KB = 0;
     for (int b : low) KB += b < 3;
     // register index c = (h << KL) | t: h bit i <-> high[i], t bit j <-> low[j] (stored at stand-in bit standin[j])
@@ -1114,7 +1526,8 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
             const dim3 gd(grid_for(std::min(per_launch, g.W - g.w0), QSV_BLOCK, 0));
             const int rc2 = k == 3 ? dispatch_lds<3, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_off)
                           : k == 4 ? dispatch_lds<4, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_off)
-                                   : dispatch_lds<5, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_off);
+                          : k == 5 ? dispatch_lds<5, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_off)
+                                   : dispatch_lds<6, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_off);
             if (rc2) return rc2;
         }
         return QSV_OK;
@@ -1142,9 +1555,95 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     return QSV_OK;
 }
 
+
+// k = 6 on the matrix cores (k_dense6_mfma).  bits[j] = bit position of matrix leg j (leg 0 most significant).
+static int launch_dense6(qsv_state *st, const int *bits, const double *m_user) {
+    constexpr int D = 64;
+    // targets on index bits 0..3 would split a wave's 16 consecutive groups: trade them for free high bits with a
+    // qubit permutation (a product of disjoint transpositions, so the same permutation undoes it afterwards)
+    std::vector<int> tb(bits, bits + 6), perm(st->n);
+    for (int b = 0; b < st->n; ++b) perm[b] = b;
+    bool moved = false;
+    for (int j = 0; j < 6; ++j)
+        if (tb[j] < 4) {
+            int e = st->n - 1;
+            while (e >= 6 && (std::find(tb.begin(), tb.end(), e) != tb.end() || perm[e] != e)) --e;
+            if (e < 6) return qsv_fail(QSV_EINVAL, "6-qubit gate: the register is too small");
+            perm[e] = tb[j];
+            perm[tb[j]] = e;
+            tb[j] = e;
+            moved = true;
+        }
+    if (moved) {
+        const int rc = qsvk_permute(st, perm.data());
+        if (rc) return rc;
+    }
+    std::vector<int> sorted(tb);
+    std::sort(sorted.begin(), sorted.end());
+    // register / matrix index c: bit i <-> sorted[i]
+    std::vector<uint64_t> off(D, 0);
+    for (int c = 0; c < D; ++c)
+        for (int i = 0; i < 6; ++i)
+            if ((c >> i) & 1) off[c] |= 1ull << sorted[i];
+    auto user_index = [&](int c) {
+        int u = 0;
+        for (int leg = 0; leg < 6; ++leg)
+            for (int i = 0; i < 6; ++i)
+                if (sorted[i] == tb[leg]) u |= ((c >> i) & 1) << (5 - leg);
+        return u;
+    };
+    bool real_matrix = true;
+    for (int i = 0; i < D * D && real_matrix; ++i) real_matrix = m_user[2 * i + 1] == 0.0;
+    std::vector<double> m(real_matrix ? D * D : 2 * D * D);  // [plane][col][row]
+    for (int r = 0; r < D; ++r)
+        for (int c = 0; c < D; ++c) {
+            const int ur = user_index(r), uc = user_index(c);
+            m[c * D + r] = m_user[2 * (ur * D + uc)];
+            if (!real_matrix) m[D * D + c * D + r] = m_user[2 * (ur * D + uc) + 1];
+        }
+    const size_t mbytes = sizeof(double) * 2 * D * D, obytes = sizeof(uint64_t) * D;
+    int rc = qsvk_ensure_matrix(st, mbytes + obytes);
+    if (rc) return rc;
+    uint64_t *dev_off = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(st->dev_matrix) + mbytes);
+    QSV_HIP(hipMemcpyAsync(st->dev_matrix, m.data(), sizeof(double) * m.size(), hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipMemcpyAsync(dev_off, off.data(), obytes, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));  // both sources are pageable host memory that dies at return
+    Mfma6Args g;
+    std::memset(&g, 0, sizeof(g));
+    g.W = st->amps >> 6;
+    g.nins = 6;
+    for (int i = 0; i < 6; ++i) g.pos[i] = static_cast<uint8_t>(sorted[i]);
+    const bool nt = st->nontemporal != 0;
+    const size_t lds = sizeof(double) * (real_matrix ? 4096 : 8192) + sizeof(uint64_t) * 64;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st->device);  // 256 if the query fails
+    const uint64_t wave_tiles = (g.W + 15) / 16;
+    const unsigned grid = static_cast<unsigned>(std::min<uint64_t>((wave_tiles + 3) / 4, 2ull * cus));
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense6_mfma<%s, %s>", nt ? "true" : "false",
+             real_matrix ? "true" : "false");
+#define QSV_LAUNCH6(N, R)                                                                                          \
+    do {                                                                                                           \
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense6_mfma<N, R>),                           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
+        hipLaunchKernelGGL((k_dense6_mfma<N, R>), dim3(grid), dim3(QSV_BLOCK), lds, st->stream, st->data, g,       \
+                           st->dev_matrix, dev_off);                                                               \
+    } while (0)
+    if (nt) { if (real_matrix) QSV_LAUNCH6(true, true); else QSV_LAUNCH6(true, false); }
+    else { if (real_matrix) QSV_LAUNCH6(false, true); else QSV_LAUNCH6(false, false); }
+#undef QSV_LAUNCH6
+    rc = check_launch();
+    if (rc) return rc;
+    return moved ? qsvk_permute(st, perm.data()) : QSV_OK;
+}
+
 int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user) {
     if (k < 1 || k > QSV_MAX_K) return qsv_fail(QSV_EINVAL, "generic gate: k must be in 1..6");
-    if (k >= 3 && k <= 5 && st->n >= k) return launch_dense_big(st, k, bits, m_user);
+    // 2^(n-6) groups must fill whole waves of 16 and the permutation needs four free bits above the lane bits
+    if (k == 6 && st->n >= 16 && st->kq_variant == 0) return launch_dense6(st, bits, m_user);
+    if (k >= 3 && k <= 6 && st->n >= k) {
+        const int rc_big = launch_dense_big(st, k, bits, m_user);
+        if (rc_big != QSV_UNHANDLED_KQ) return rc_big;
+    }
     const size_t bytes = sizeof(double) * 2ull << (2 * k);
     int rc = qsvk_ensure_matrix(st, bytes);
     if (rc) return rc;
@@ -1278,6 +1777,12 @@ int qsvk_diag(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits
     QSV_HIP(hipMemcpyAsync(dpos, pos, 8, hipMemcpyHostToDevice, st->stream));
     // the two pageable-source copies above are staged before return (HIP semantics), so `table` may die
     QSV_HIP(hipStreamSynchronize(st->stream));
+    if (st->n >= RO_MIN_QUBITS && st->readout_variant == 0) {
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_diag_table_s");
+        hipLaunchKernelGGL(k_diag_table_s, dim3(static_cast<unsigned>(st->amps / (QSV_BLOCK * RO_ITEMS))), dim3(QSV_BLOCK), 0,
+                           st->stream, st->data, st->amps, K, dpos, st->dev_matrix);
+        return check_launch();
+    }
     const int grid = grid_for(st->amps, QSV_BLOCK, 4096);
     snprintf(st->last_kernel, sizeof(st->last_kernel), "k_diag_table");
     hipLaunchKernelGGL(k_diag_table, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, K, dpos,
@@ -1306,6 +1811,21 @@ int qsvk_phase(qsv_state *st, int nctrl, const int *cbits, double re, double im)
 }
 
 int qsvk_measure_probs(qsv_state *st, int bit, const double e0[4], const double e1[4], double *p0, double *p1) {
+    if (st->n >= RO_MIN_QUBITS && st->readout_variant == 0) {
+        const int grid = grid_for(st->amps >> (bit < QSV_LANE_BITS ? 0 : 1), QSV_BLOCK * RO_ITEMS, QSV_REDUCE_BLOCKS);
+        const cplx a{e0[0], e0[1]}, b{e0[2], e0[3]}, c{e1[0], e1[1]}, d{e1[2], e1[3]};
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_measure_probs_s<%s>", bit < QSV_LANE_BITS ? "true" : "false");
+        if (bit < QSV_LANE_BITS)
+            hipLaunchKernelGGL(k_measure_probs_s<true>, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, bit,
+                               a, b, c, d, st->partials);
+        else
+            hipLaunchKernelGGL(k_measure_probs_s<false>, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, bit,
+                               a, b, c, d, st->partials);
+        int rc = check_launch();
+        if (rc) return rc;
+        return sum_partials(st, grid, p0, p1);
+    }
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_measure_probs");
     const uint64_t pairs = st->amps >> 1;
     const int grid = grid_for(pairs, QSV_BLOCK * 8, QSV_REDUCE_BLOCKS);
     hipLaunchKernelGGL(k_measure_probs, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, pairs, bit,
@@ -1326,9 +1846,21 @@ int qsvk_collapse(qsv_state *st, int bit, const double e[4], double scale) {
     amp_t *fresh = nullptr;
     int rc = qsvk_scratch(st, pairs, &fresh);
     if (rc) return rc;
-    const int grid = grid_for(pairs, QSV_BLOCK * 4, 8192);
-    hipLaunchKernelGGL(k_collapse, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, pairs, bit,
-                       cplx{e[0], e[1]}, cplx{e[2], e[3]}, scale);
+    if (st->n >= RO_MIN_QUBITS && st->readout_variant == 0) {
+        const dim3 gd(static_cast<unsigned>(pairs / (QSV_BLOCK * RO_ITEMS))), bd(QSV_BLOCK);
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_collapse_s<%s>", bit < QSV_LANE_BITS ? "true" : "false");
+        if (bit < QSV_LANE_BITS)
+            hipLaunchKernelGGL(k_collapse_s<true>, gd, bd, 0, st->stream, st->data, fresh, pairs, bit, cplx{e[0], e[1]},
+                               cplx{e[2], e[3]}, scale);
+        else
+            hipLaunchKernelGGL(k_collapse_s<false>, gd, bd, 0, st->stream, st->data, fresh, pairs, bit, cplx{e[0], e[1]},
+                               cplx{e[2], e[3]}, scale);
+    } else {
+        const int grid = grid_for(pairs, QSV_BLOCK * 4, 8192);
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_collapse");
+        hipLaunchKernelGGL(k_collapse, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, pairs, bit,
+                           cplx{e[0], e[1]}, cplx{e[2], e[3]}, scale);
+    }
     rc = check_launch();
     if (rc) return rc;
     st->n -= 1;
@@ -1342,9 +1874,21 @@ int qsvk_insert(qsv_state *st, int bit, const double amp[4]) {
     amp_t *fresh = nullptr;
     int rc = qsvk_scratch(st, out_amps, &fresh);
     if (rc) return rc;
-    const int grid = grid_for(out_amps, QSV_BLOCK * 4, 8192);
-    hipLaunchKernelGGL(k_insert, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, out_amps, bit,
-                       cplx{amp[0], amp[1]}, cplx{amp[2], amp[3]});
+    if (st->n >= RO_MIN_QUBITS && st->readout_variant == 0) {
+        const dim3 gd(static_cast<unsigned>(st->amps / (QSV_BLOCK * RO_ITEMS))), bd(QSV_BLOCK);
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_insert_s<%s>", bit < QSV_LANE_BITS ? "true" : "false");
+        if (bit < QSV_LANE_BITS)
+            hipLaunchKernelGGL(k_insert_s<true>, gd, bd, 0, st->stream, st->data, fresh, st->amps, bit,
+                               cplx{amp[0], amp[1]}, cplx{amp[2], amp[3]});
+        else
+            hipLaunchKernelGGL(k_insert_s<false>, gd, bd, 0, st->stream, st->data, fresh, st->amps, bit,
+                               cplx{amp[0], amp[1]}, cplx{amp[2], amp[3]});
+    } else {
+        const int grid = grid_for(out_amps, QSV_BLOCK * 4, 8192);
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_insert");
+        hipLaunchKernelGGL(k_insert, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, out_amps, bit,
+                           cplx{amp[0], amp[1]}, cplx{amp[2], amp[3]});
+    }
     rc = check_launch();
     if (rc) return rc;
     st->n += 1;
@@ -1359,8 +1903,41 @@ int qsvk_permute(qsv_state *st, const int *src_bit_of_dst_bit) {
     amp_t *fresh = nullptr;
     int rc = qsvk_scratch(st, st->amps, &fresh);
     if (rc) return rc;
-    const int grid = grid_for(st->amps, QSV_BLOCK * 4, 8192);
-    hipLaunchKernelGGL(k_permute, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, st->amps, g);
+    if (st->n >= RO_MIN_QUBITS && st->readout_variant == 0) {
+        // the tile: destination bits 0..2, the destinations of source bits 0..2, then the lowest other bits up to six
+        PermTileArgs t;
+        std::memset(&t, 0, sizeof(t));
+        t.tiles = st->amps >> 6;
+        t.bytes = (st->n + 7) / 8;
+        std::vector<int> tile = {0, 1, 2};
+        for (int j = 3; j < st->n; ++j)
+            if (src_bit_of_dst_bit[j] < 3) tile.push_back(j);
+        for (int j = 3; j < st->n && tile.size() < 6; ++j)
+            if (std::find(tile.begin(), tile.end(), j) == tile.end()) tile.push_back(j);
+        std::sort(tile.begin(), tile.end());
+        for (int k = 0; k < 6; ++k) {
+            t.tile_dst[k] = static_cast<uint8_t>(tile[k]);
+            t.tile_src[k] = static_cast<uint8_t>(src_bit_of_dst_bit[tile[k]]);
+        }
+        // lut[b][v]: where the destination-index bits 8b .. 8b+7 (value v) come from in the source index
+        std::vector<uint64_t> lut(static_cast<size_t>(t.bytes) * 256, 0);
+        for (int b = 0; b < t.bytes; ++b)
+            for (int v = 0; v < 256; ++v)
+                for (int i = 0; i < 8 && 8 * b + i < st->n; ++i)
+                    if ((v >> i) & 1) lut[b * 256 + v] |= 1ull << src_bit_of_dst_bit[8 * b + i];
+        rc = qsvk_ensure_matrix(st, sizeof(uint64_t) * lut.size());
+        if (rc) return rc;
+        QSV_HIP(hipMemcpyAsync(st->dev_matrix, lut.data(), sizeof(uint64_t) * lut.size(), hipMemcpyHostToDevice, st->stream));
+        QSV_HIP(hipStreamSynchronize(st->stream));  // `lut` dies at return
+        const int grid = grid_for(t.tiles, (QSV_BLOCK / 64) * RO_ITEMS, 1 << 16);
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_permute_s");
+        hipLaunchKernelGGL(k_permute_s, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, t,
+                           reinterpret_cast<const uint64_t *>(st->dev_matrix));
+    } else {
+        const int grid = grid_for(st->amps, QSV_BLOCK * 4, 8192);
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_permute");
+        hipLaunchKernelGGL(k_permute, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, st->amps, g);
+    }
     rc = check_launch();
     if (rc) return rc;
     return adopt(st, fresh, st->amps);
@@ -1381,6 +1958,100 @@ int qsvk_inner(qsv_state *a, qsv_state *b, double *re, double *im) {
     int rc = check_launch();
     if (rc) return rc;
     return sum_partials(a, grid, re, im);
+}
+
+
+// rho_out: 4^k complex, row-major, row / column index bit (k-1-j) <-> bits[j] (bits[0] = most significant leg).
+int qsvk_reduced_density(qsv_state *st, int k, const int *bits, double *rho_out) {
+    if (k < 1 || k > QSV_MAX_K || k > st->n) return qsv_fail(QSV_EINVAL, "reduced density matrix: keep 1..6 qubits");
+    const int D = 1 << k;
+    std::vector<int> sorted(bits, bits + k);
+    std::sort(sorted.begin(), sorted.end());
+    const int T = D <= 16 ? 1 : D <= 32 ? 2 : 4, P = T * (T + 1) / 2;
+    std::vector<uint64_t> off(16 * T, 0);
+    for (int r = 0; r < D; ++r)
+        for (int i = 0; i < k; ++i)
+            if ((r >> i) & 1) off[r] |= 1ull << sorted[i];
+    RdmArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.W = st->amps >> k;
+    g.nins = k;
+    g.D = D;
+    for (int i = 0; i < k; ++i) g.pos[i] = static_cast<uint8_t>(sorted[i]);
+    const bool big = st->n >= RO_MIN_QUBITS && g.W % 4 == 0;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st->device);  // 256 if the query fails
+    const int blocks = big ? static_cast<int>(std::min<uint64_t>(2ull * cus, std::max<uint64_t>(1, (g.W >> 2) / 4))) : 0;
+    const int entries = big ? P * 2 * 256 : 2 * D * D;
+    const size_t b_off = sizeof(uint64_t) * off.size(), b_out = sizeof(double) * entries,
+                 b_part = sizeof(double) * static_cast<size_t>(blocks) * entries;
+    int rc = qsvk_ensure_matrix(st, b_off + b_out + b_part + 64);
+    if (rc) return rc;
+    char *p = reinterpret_cast<char *>(st->dev_matrix);
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(p);
+    double *d_out = reinterpret_cast<double *>(p + b_off), *d_part = reinterpret_cast<double *>(p + b_off + b_out);
+    QSV_HIP(hipMemcpyAsync(d_off, off.data(), b_off, hipMemcpyHostToDevice, st->stream));
+    std::vector<double> raw(entries);
+    if (big) {
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_rdm<%d>", T);
+        if (T == 1) hipLaunchKernelGGL(k_rdm<1>, dim3(blocks), dim3(QSV_BLOCK), 0, st->stream, st->data, g, d_off, d_part);
+        else if (T == 2) hipLaunchKernelGGL(k_rdm<2>, dim3(blocks), dim3(QSV_BLOCK), 0, st->stream, st->data, g, d_off, d_part);
+        else hipLaunchKernelGGL(k_rdm<4>, dim3(blocks), dim3(QSV_BLOCK), 0, st->stream, st->data, g, d_off, d_part);
+        rc = check_launch();
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_sum_partials, dim3((entries + QSV_BLOCK - 1) / QSV_BLOCK), dim3(QSV_BLOCK), 0, st->stream, d_part,
+                           blocks, entries, d_out);
+    } else {
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_rdm_small");
+        hipLaunchKernelGGL(k_rdm_small, dim3((D * D + QSV_BLOCK - 1) / QSV_BLOCK), dim3(QSV_BLOCK), 0, st->stream, st->data, g,
+                           d_off, d_out);
+    }
+    rc = check_launch();
+    if (rc) return rc;
+    QSV_HIP(hipMemcpyAsync(raw.data(), d_out, b_out, hipMemcpyDeviceToHost, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));
+    // kernel order (row bit i <-> sorted[i]) -> caller order (bit k-1-j <-> bits[j])
+    auto user_index = [&](int c) {
+        int u = 0;
+        for (int leg = 0; leg < k; ++leg)
+            for (int i = 0; i < k; ++i)
+                if (sorted[i] == bits[leg]) u |= ((c >> i) & 1) << (k - 1 - leg);
+        return u;
+    };
+    for (int r = 0; r < D; ++r)
+        for (int c = 0; c < D; ++c) {
+            double vr, vi;
+            if (big) {
+                // tile pair p = (ti <= tj); D layout: col = lane & 15, row = (lane >> 4) + 4 reg
+                const bool upper = r / 16 <= c / 16;
+                const int rr = upper ? r : c, cc = upper ? c : r;
+                const int ti = rr / 16, tj = cc / 16;
+                int pidx = 0;
+                for (int a = 0; a < ti; ++a) pidx += T - a;
+                pidx += tj - ti;
+                const int row = rr % 16, col = cc % 16, reg = row / 4, lane = (row % 4) * 16 + col;
+                vr = raw[((pidx * 2 + 0) * 4 + reg) * 64 + lane];
+                vi = raw[((pidx * 2 + 1) * 4 + reg) * 64 + lane];
+                if (!upper) vi = -vi;  // rho[r][c] = conj(rho[c][r])
+            } else {
+                vr = raw[2 * (r * D + c)];
+                vi = raw[2 * (r * D + c) + 1];
+            }
+            const int ur = user_index(r), uc = user_index(c);
+            rho_out[2 * (ur * D + uc)] = vr;
+            rho_out[2 * (ur * D + uc) + 1] = vi;
+        }
+    return QSV_OK;
+}
+
+int qsvk_expect_density(qsv_state *ket, qsv_state *rho, double *re, double *im) {
+    QSV_HIP(hipStreamSynchronize(ket->stream));
+    const int grid = grid_for(rho->amps, QSV_BLOCK * 8, QSV_REDUCE_BLOCKS);
+    hipLaunchKernelGGL(k_expect_density, dim3(grid), dim3(QSV_BLOCK), 0, rho->stream, ket->data, rho->data,
+                       static_cast<uint64_t>(ket->n), rho->partials);
+    int rc = check_launch();
+    if (rc) return rc;
+    return sum_partials(rho, grid, re, im);
 }
 
 int qsvk_expect_pauli(qsv_state *st, uint64_t xmask, uint64_t zmask, int n_y, double *re, double *im) {

@@ -601,7 +601,7 @@ static int launch_plane(qsv_state *st, uint64_t d, uint64_t L, int nblocks, cons
     g.batch_amps = static_cast<uint32_t>(used);
     g.stride = static_cast<int32_t>(stride);
     int cus = 256;
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st->device);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st->device);  // 256 if the query fails
     const unsigned grid = static_cast<unsigned>(std::min<uint64_t>(g.batches, static_cast<uint64_t>(cus)));
     const bool nt = st->nontemporal != 0;
     const int cstride = (stride == 31 || stride == -31) ? static_cast<int>(stride) : 0;

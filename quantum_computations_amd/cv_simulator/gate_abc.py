@@ -17,7 +17,7 @@ import logging
 
 from .mps import MPS, SVD_OPTIONS
 
-logger = logging.getLogger(__name__)
+logger = logging.getLogger("simulators." + __name__.split(".", 1)[1])
 
 #: digits shown for floating-point gate arguments in ``repr``
 REPR_DIGITS = 5

@@ -30,7 +30,7 @@ from .mps import MPS
 from .states import State  # noqa: F401  (re-exported, as upstream)
 from .utils import fourier_matrix, plane_resample_table, rotation_matrix, sinc_matrix
 
-logger = logging.getLogger(__name__)
+logger = logging.getLogger("simulators." + __name__.split(".", 1)[1])
 
 
 def _truncation(gate, mps, rng=None) -> dict:

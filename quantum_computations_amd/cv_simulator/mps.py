@@ -1,12 +1,14 @@
 """Register of the CV simulator behind the reference's ``MPS`` surface, in HBM, in one of two layouts.
 
-``layout="dense"`` (default) holds the *contracted* tensor ``psi[q_0, ..., q_{m-1}]`` as a ``QuditState``
-(``d = len(domain)`` levels per mode): every gate is one bandwidth-bound pass, results equal the reference's with
-truncation disabled (``rel_err = 0``), truncation keywords are ignored, and the size is limited by ``d^m * 16`` bytes.
-
-``layout="sites"`` is the reference's own data structure -- a chain of ``(chi_l, d, chi_r)`` site tensors
+``layout="sites"`` (default) is the reference's own data structure -- a chain of ``(chi_l, d, chi_r)`` site tensors
 (``simulators/cv_simulator/mps.py:102-201``) re-compressed with a truncated SVD after every two-mode gate -- kept on the
-device by ``site_register.SiteRegister``; this is what reaches the reference's d = 1000 grids.
+device by ``site_register.SiteRegister``; this is what reaches the reference's d = 1000 grids, what
+honours the truncation keywords, and what a script written for the reference gets when it calls ``MPS(qs, tensors)``.
+
+``layout="dense"`` (opt-in) holds the *contracted* tensor ``psi[q_0, ..., q_{m-1}]`` as a ``QuditState``
+(``d = len(domain)`` levels per mode): every gate is one bandwidth-bound pass, results equal the reference's with
+truncation disabled (``rel_err = 0``), truncation keywords are ignored, and the size is limited by ``d^m * 16`` bytes
+(the Fock-truncated configuration of BASELINE.json, ``cv_simulator.fock``, is this kind of register).
 
 Either way the class keeps the constructor, ``domain`` / ``diff``, ``len``, ``copy``, ``validate``, ``contract``,
 ``norm`` and ``partial_density_mps`` of the reference class, and the gate classes drive both through the same calls.
@@ -47,10 +49,11 @@ SVD_OPTIONS = {name: p for name, p in inspect.signature(tensor_svd).parameters.i
 
 
 class MPS:
-    def __init__(self, domain: np.ndarray, tensors: list[np.ndarray], *, device: int = 0, layout: str = "dense"):
+    def __init__(self, domain: np.ndarray, tensors: list[np.ndarray], *, device: int = 0, layout: str = "sites"):
         """``tensors``: one entry per mode -- a wavefunction on ``domain`` (1-D) or an MPS site ``(chi_l, d, chi_r)``.
-        ``layout="dense"``: the sites are contracted on the host (small registers) and the dense tensor is uploaded;
-        ``layout="sites"``: the sites are uploaded as they are and stay a matrix-product state."""
+        ``layout="sites"`` (the reference's behaviour): the sites are uploaded as they are and stay a matrix-product
+        state; ``layout="dense"``: the sites are contracted on the host (small registers) and the dense tensor is
+        uploaded."""
         if layout not in ("dense", "sites"):
             raise ValueError("layout must be 'dense' or 'sites'")
         self.domain: np.ndarray = domain
@@ -77,9 +80,31 @@ class MPS:
         out.reg = reg
         return out
 
-    # ---- container protocol ------------------------------------------------------------------------
+    # ---- container protocol (the reference class is a list of site tensors, mps.py:102-134) ----------
     def __len__(self):
         return self.reg.dims[0]
+
+    def _sites_only(self, what: str):
+        if self.layout != "sites":
+            raise AttributeError(f"a dense register has no site tensors ({what}): build the MPS with layout='sites'")
+
+    def __getitem__(self, index):
+        """Host copy of site ``index`` (or of a slice of sites)."""
+        self._sites_only("indexing")
+        picked = self.reg.sites[index]
+        return [t.cpu().numpy() for t in picked] if isinstance(index, slice) else picked.cpu().numpy()
+
+    def __setitem__(self, index: int, tensor: np.ndarray) -> None:
+        """Replace site ``index`` (uploaded; shapes are the caller's responsibility until :meth:`validate`)."""
+        self._sites_only("item assignment")
+        tensor = np.asarray(tensor)
+        if tensor.ndim != 3:
+            raise ValueError(f"Tensor at index {index} does not have exactly three axes.")
+        self.reg.sites[index] = self.reg._upload(tensor)
+
+    def __iter__(self):
+        self._sites_only("iteration")
+        return iter(self.reg.site_arrays())
 
     def copy(self) -> "MPS":
         return MPS._wrap(self.domain.copy(), self.reg.copy())
@@ -91,8 +116,7 @@ class MPS:
     @property
     def tensors(self) -> list[np.ndarray]:
         """Host copies of the site tensors (``layout="sites"`` only; the dense register has no sites)."""
-        if self.layout != "sites":
-            raise AttributeError("a dense register has no site tensors: build the MPS with layout='sites'")
+        self._sites_only("tensors")
         return self.reg.site_arrays()
 
     def shape(self):

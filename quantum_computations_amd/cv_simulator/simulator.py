@@ -16,7 +16,7 @@ import numpy as np
 from .gate_abc import Gate, MeasurementResult
 from .mps import MPS, SVD_OPTIONS
 
-logger = logging.getLogger(__name__)
+logger = logging.getLogger("simulators." + __name__.split(".", 1)[1])
 
 
 def format_time(time_in_seconds: float) -> str:

@@ -12,7 +12,7 @@ import logging
 import numpy as np
 import scipy.fft as fft
 
-logger = logging.getLogger(__name__)
+logger = logging.getLogger("simulators." + __name__.split(".", 1)[1])
 
 
 def _spacing(xs: np.ndarray) -> float:

@@ -267,6 +267,23 @@ class DeviceState:
         _lib.call("qsv_inner", self._h, other._h, C.byref(re), C.byref(im))
         return complex(re.value, im.value)
 
+    def reduced_density(self, qubits) -> np.ndarray:
+        """Reduced density matrix of ``qubits`` (at most six; everything else traced out) as a host
+        ``(2^k, 2^k)`` array, ``qubits[0]`` the most significant bit of both indices.  One read pass on the device."""
+        qubits = [int(q) for q in qubits]
+        if not 1 <= len(qubits) <= 6:
+            raise ValueError("keep between 1 and 6 qubits")
+        dim = 1 << len(qubits)
+        out = np.empty((dim, dim), dtype=np.complex128)
+        _lib.call("qsv_reduced_density", self._h, len(qubits), _ints(qubits), _ptr(out))
+        return out
+
+    def expect_density(self, rho: "DensityState") -> complex:
+        """``<self| rho |self>`` for a density matrix held on the device (the ket / matrix branch of ``npq.fidelity``)."""
+        re, im = C.c_double(), C.c_double()
+        _lib.call("qsv_expect_density", self._h, rho._h, C.byref(re), C.byref(im))
+        return complex(re.value, im.value)
+
     # ---- timing (HIP events on the register's stream) -----------------------------------------
     def timer_start(self) -> None:
         _lib.call("qsv_timer_start", self._h)
@@ -291,6 +308,64 @@ class DeviceState:
         ms = C.c_float()
         _lib.call("qsv_event_elapsed_ms", self._h, int(slot_a), int(slot_b), C.byref(ms))
         return ms.value
+
+
+class DensityState(DeviceState):
+    """An n-qubit density matrix in HBM: ``rho`` flattened row-major is a 2n-qubit register whose first n qubits index
+    the row and whose last n the column -- the layout ``Gate.apply`` uses for ``U rho U^dagger`` (gates.py:51-52), kept
+    on the device between gates.  ``ndim == 2`` like the ndarray it stands for."""
+
+    ndim = 2
+
+    @classmethod
+    def from_numpy(cls, rho: np.ndarray, device: int = 0) -> "DensityState":
+        rho = np.asarray(rho)
+        if rho.ndim != 2 or rho.shape[0] != rho.shape[1]:
+            raise ValueError("State has wrong dimensions.")
+        flat = DeviceState.from_numpy(np.ascontiguousarray(rho).reshape(-1), device)
+        out = cls(flat._h, device=flat.device)
+        flat._h = None
+        return out
+
+    @classmethod
+    def from_ket(cls, ket: np.ndarray, device: int = 0) -> "DensityState":
+        ket = np.asarray(ket)
+        return cls.from_numpy(np.multiply.outer(ket, ket.conj()), device)
+
+    @property
+    def num_qubits(self) -> int:
+        return super().num_qubits // 2
+
+    @property
+    def shape(self) -> tuple[int, int]:
+        dim = 1 << self.num_qubits
+        return (dim, dim)
+
+    def to_numpy(self) -> np.ndarray:
+        return super().to_numpy().reshape(self.shape)
+
+    def copy(self) -> "DensityState":
+        twin = DeviceState.copy(self)
+        out = DensityState(twin._h, device=twin.device)
+        twin._h = None
+        return out
+
+    def apply_matrix(self, matrix: np.ndarray, indices) -> "DensityState":
+        """``U rho U^dagger``: ``U`` on the row qubits, ``conj(U)`` on the column qubits."""
+        n = self.num_qubits
+        indices = [int(i) for i in indices]
+        if any(not 0 <= q < n for q in indices):
+            raise ValueError(f"qubit index out of range for a {n}-qubit register")
+        DeviceState.apply_matrix(self, matrix, indices)
+        DeviceState.apply_matrix(self, np.conjugate(matrix), [n + q for q in indices])
+        return self
+
+    def purity(self) -> float:
+        """``tr(rho rho)`` for a hermitian ``rho`` (``npq.purity``): the squared norm of the flattened register."""
+        return self.norm2()
+
+    def fidelity_with_ket(self, ket: DeviceState) -> float:
+        return ket.expect_density(self).real
 
 
 class QuditState:

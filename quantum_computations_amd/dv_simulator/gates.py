@@ -23,7 +23,8 @@ REPR_DIGITS = 5
 
 
 def is_device_register(state) -> bool:
-    """A register that lives in HBM: a ``DeviceState`` or a ``distributed.ShardedState`` (same gate methods)."""
+    """A register that lives in HBM: a ``DeviceState`` (ket), a ``DensityState`` (density matrix: its ``apply_matrix``
+    does ``U rho U^dagger``) or a ``distributed.ShardedState`` (same gate methods)."""
     return isinstance(state, DeviceState) or (not isinstance(state, np.ndarray) and hasattr(state, "apply_matrix"))
 
 

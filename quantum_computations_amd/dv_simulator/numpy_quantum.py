@@ -178,8 +178,28 @@ def compare_kets(a: np.ndarray, b: np.ndarray) -> bool:
     return np.allclose(ket2dm(normalise(a)), ket2dm(normalise(b)))
 
 
-def fidelity(a: np.ndarray, b: np.ndarray) -> float:
-    """Fidelity between any mix of kets and (hermitian) density matrices."""
+def fidelity(a, b) -> float:
+    """Fidelity between any mix of kets and (hermitian) density matrices (numpy_quantum.py:148-161).  Host arrays
+    as in the reference; registers in HBM (``DeviceState`` kets, ``DensityState`` matrices) are reduced on the device
+    -- ket/ket by one pass over both, ket/matrix by one pass over the matrix -- and never downloaded.  Two device
+    density matrices need the spectrum of ``a @ b`` and go through the host (they are 4^n numbers: small n only)."""
+    from ..device import DensityState, DeviceState
+    if isinstance(a, DeviceState) or isinstance(b, DeviceState):
+        if not (isinstance(a, DeviceState) and isinstance(b, DeviceState)):
+            def lift(x, like):
+                if isinstance(x, DeviceState):
+                    return x
+                x = np.asarray(x)
+                return (DeviceState if x.ndim == 1 else DensityState).from_numpy(x, like.device)
+            a, b = lift(a, b if isinstance(b, DeviceState) else a), lift(b, a if isinstance(a, DeviceState) else b)
+        kinds = (a.ndim, b.ndim)
+        if kinds == (1, 1):
+            return abs(a.inner(b)) ** 2
+        if kinds == (1, 2):
+            return a.expect_density(b).real
+        if kinds == (2, 1):
+            return b.expect_density(a).real
+        a, b = a.to_numpy(), b.to_numpy()
     kinds = (a.ndim, b.ndim)
     if kinds == (1, 1):
         return np.abs(np.vdot(a, b)).real ** 2
@@ -191,7 +211,11 @@ def fidelity(a: np.ndarray, b: np.ndarray) -> float:
     return np.sqrt(spectrum).sum() ** 2
 
 
-def purity(rho: np.ndarray) -> float:
+def purity(rho) -> float:
+    """``tr(rho rho)`` of a hermitian density matrix (numpy_quantum.py:164-166); a ``DensityState`` is reduced on
+    the device."""
+    if hasattr(rho, "purity"):
+        return rho.purity()
     return np.trace(rho @ rho).real
 
 

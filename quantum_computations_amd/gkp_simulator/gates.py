@@ -24,7 +24,7 @@ from ..cv_simulator.mps import SVD_OPTIONS
 from .insert_bell import GKPBellState, InsertBell
 from .utils import PI, SQPI
 
-logger = logging.getLogger(__name__)
+logger = logging.getLogger("simulators." + __name__.split(".", 1)[1])
 
 Syndrome = tuple[int, int]
 

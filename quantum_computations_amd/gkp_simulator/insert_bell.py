@@ -16,7 +16,7 @@ from ..cv_simulator.gates import Insert
 from ..cv_simulator.mps import MPS
 from ..cv_simulator.states import State
 
-logger = logging.getLogger(__name__)
+logger = logging.getLogger("simulators." + __name__.split(".", 1)[1])
 
 PI = np.pi
 SQPI = np.sqrt(np.pi)

@@ -24,7 +24,7 @@ from .gates import SQPI, Syndrome  # noqa: F401
 from .transpiler import ClassicalControl, MBGKPCircuit, MeasurementBased, gate_transpile
 from .utils import format_result
 
-logger = logging.getLogger(__name__)
+logger = logging.getLogger("simulators." + __name__.split(".", 1)[1])
 
 
 def measurement_formatter(result: MeasurementResult) -> str:

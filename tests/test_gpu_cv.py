@@ -140,7 +140,15 @@ def test_mps_facade(golden):
     # constructor from site tensors (vectors and (chi_l, d, chi_r) sites)
     a, b = State.VACUUM.eval(qs), State.GKP_ZERO.eval(qs, 0.3)
     prod = MPS(qs, [a, b])
+    assert prod.layout == "sites"                      # the reference's data structure is the default
     assert maxdiff(prod.contract(), np.multiply.outer(a, b)) < 1e-15
+    # ... and behaves like the reference's list of site tensors
+    assert prod[0].shape == (1, 16, 1) and [t.shape for t in prod] == [(1, 16, 1), (1, 16, 1)]
+    assert [t.shape for t in prod[0:2]] == [t.shape for t in prod.tensors]
+    prod[1] = (2 * b).reshape(1, -1, 1)
+    assert maxdiff(prod.contract(), 2 * np.multiply.outer(a, b)) < 1e-15
+    with pytest.raises(AttributeError):
+        MPS(qs, [a, b], layout="dense")[0]
     with pytest.raises(ValueError):
         MPS(qs, [np.ones((2, 16, 1))])
     with pytest.raises(TypeError):

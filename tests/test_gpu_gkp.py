@@ -58,7 +58,7 @@ def test_bell_pairs_and_insertion(ref):
     with pytest.raises(IndexError):
         InsertBell(7, gkp_epsilon=eps).apply(ends)
     with pytest.raises(NotImplementedError):
-        InsertBell(0, gkp_epsilon=eps).apply(MPS(small, [CVState.VACUUM.eval(small)]))
+        InsertBell(0, gkp_epsilon=eps).apply(MPS(small, [CVState.VACUUM.eval(small)], layout="dense"))
 
 
 def test_gadgets_with_forced_outcomes(ref):
@@ -104,7 +104,7 @@ def test_logical_readout_of_product_states(ref):
     for n_modes, names in [(1, ["GKP_T"]), (2, ["GKP_H", "GKP_MINUS"])]:
         sites = MPS(qs, [CVState[s].eval(qs, eps) for s in names], layout="sites")
         assert maxdiff(U.full_logical_density_mps(sites), g[f"rho_product_{n_modes}"]) < 1e-10
-        dense = MPS(qs, [CVState[s].eval(qs, eps) for s in names])
+        dense = MPS(qs, [CVState[s].eval(qs, eps) for s in names], layout="dense")
         assert maxdiff(U.full_logical_density_mps(dense), g[f"rho_product_{n_modes}"]) < 1e-10
     psi = np.multiply.outer(CVState.GKP_H.eval(qs, eps), CVState.GKP_MINUS.eval(qs, eps))
     assert maxdiff(U.full_logical_density(qs, psi), g["rho_product_2"]) < 1e-9

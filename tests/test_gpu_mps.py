@@ -76,7 +76,7 @@ def test_site_layout_agrees_with_dense_layout_when_nothing_is_truncated(golden):
     g = golden["cv_mps"]
     qs = g["qs"]
     exact = {"rel_err": 0.0, "abs_err": 0.0}
-    sites, dense = MPS(qs, [], layout="sites"), MPS(qs, [])
+    sites, dense = MPS(qs, [], layout="sites"), MPS(qs, [], layout="dense")
     for gate in cv_mps_program(CV, State, exact)[:14]:
         gate.apply(sites, rng=None)
         gate.apply(dense, rng=None)

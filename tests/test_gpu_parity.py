@@ -246,6 +246,28 @@ def test_generic_kq(n, k):
     assert maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL
 
 
+def test_six_qubit_gates_on_the_matrix_cores():
+    """k = 6 on registers of 16+ qubits runs on the f64 matrix cores (k_dense6_mfma): complex and real 64 x 64
+    matrices, targets all high, mixed, and with up to four of them on index bits 0..3 (moved out of the way by a
+    qubit permutation before and after), legs in any order; against the oracle."""
+    n = 16
+    rng = np.random.default_rng(66)
+    ket = W.random_ket(n, 66)
+    dev = DeviceState.from_numpy(ket)
+    want = ket
+    cases = [[6, 8, 9, 11, 13, 15], [4, 5, 7, 10, 12, 14], [0, 6, 7, 9, 12, 15], [0, 1, 2, 3, 4, 5], [1, 3, 5, 8, 10, 14],
+             [15, 14, 13, 12, 11, 10], [2, 3, 9, 4, 0, 15]]
+    for i, bits in enumerate(cases):
+        bits = list(bits)
+        rng.shuffle(bits)
+        qs = [n - 1 - b for b in bits]
+        u = W.haar_unitary(64, rng) if i % 2 == 0 else np.linalg.qr(rng.standard_normal((64, 64)))[0]
+        dev.apply_matrix(u, qs)
+        assert dev.last_kernel().startswith("k_dense6_mfma<") or dev.last_kernel() == "k_permute_s", dev.last_kernel()
+        want = O.apply_gate(want, u, qs)
+        assert maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL, bits
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("k", [3, 4, 5])
 def test_register_blocked_kq_every_low_target_set(k, variant):
@@ -301,6 +323,68 @@ def test_measure_insert_every_position(n):
     for q in range(n + 1):
         out = G.Insert(q, State.TDG).apply(ket)
         assert maxdiff(out, O.insert_qubit(ket, q, State.TDG.get())) < GATE_TOL, q
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_streaming_readout_kernels_every_position(variant):
+    """Registers of 2^14 amplitudes and more run the streaming forms of measurement / insertion / permutation /
+    table diagonals (``variant`` 0; 1 forces the plain grid-stride forms the small-register tests above exercise):
+    every qubit position -- lane bits resolved by wave shuffles and lane gathers, high bits by paired streams --
+    against the oracle."""
+    from quantum_computations_amd import _lib
+    n = 15
+    ket = W.random_ket(n, 77)
+    rng = np.random.default_rng(7)
+    names = set()
+    for q in range(n):
+        theta, phi, result = [(0.0, 0.0, 0), (np.pi / 2, 0.0, 1), (0.9, 2.2, 1)][q % 3]
+        dev = DeviceState.from_numpy(ket)
+        dev.set_option(_lib.OPT_READOUT_VARIANT, variant)
+        eigs = G.M(q, theta, phi).eigenvectors()
+        p = dev.measure_probs(q, *eigs)
+        names.add(dev.last_kernel())
+        want, _ = O.measure(ket, q, theta, phi, result)
+        want_p = [nrm ** 2 for _, nrm in O.measure_branches(ket, q, theta, phi)]
+        out, s = G.M(q, theta, phi, result=result).apply(dev)
+        names.add(out.last_kernel())
+        assert s == result and maxdiff(out.to_numpy(), want) < GATE_TOL * 10, (q, theta, phi)
+        assert maxdiff(np.array(p), np.array(want_p)) < 1e-13, (q, p, want_p)
+        out.insert(q, State.TDG.get())                        # back to n qubits at the same place
+        names.add(out.last_kernel())
+        assert maxdiff(out.to_numpy(), O.insert_qubit(want, q, State.TDG.get())) < GATE_TOL * 10, q
+    dev = DeviceState.from_numpy(ket)
+    dev.set_option(_lib.OPT_READOUT_VARIANT, variant)
+    dev.insert(n, [0.6, 0.8j])                                # a new least significant qubit, and a new top one
+    dev.insert(0, [0.8, -0.6])
+    want = O.insert_qubit(O.insert_qubit(ket, n, np.array([0.6, 0.8j])), 0, np.array([0.8, -0.6]))
+    assert maxdiff(dev.to_numpy(), want) < GATE_TOL
+    for trial in range(8):
+        order = [int(v) for v in rng.permutation(n)]
+        if trial == 0:
+            order = list(range(n))
+        elif trial == 1:
+            order = list(range(n - 3)) + [n - 1, n - 3, n - 2]          # only bits inside a 128-byte line move
+        elif trial == 2:
+            order = list(range(n))[::-1]
+        elif trial == 3:
+            order = list(range(3, n)) + [0, 1, 2]
+        dev = DeviceState.from_numpy(ket)
+        dev.set_option(_lib.OPT_READOUT_VARIANT, variant)
+        dev.permute(order)
+        names.add(dev.last_kernel())
+        assert np.array_equal(dev.to_numpy(), O.permute_qubits(ket, order)), order
+    for k in (3, 4, 6):
+        qs = [int(v) for v in rng.choice(n, size=k, replace=False)]
+        d = np.exp(1j * rng.uniform(0, 6.28, 1 << k))
+        dev = DeviceState.from_numpy(ket)
+        dev.set_option(_lib.OPT_READOUT_VARIANT, variant)
+        dev.apply_matrix(np.diag(d), qs)
+        names.add(dev.last_kernel())
+        assert maxdiff(dev.to_numpy(), O.apply_gate(ket, np.diag(d), qs)) < GATE_TOL
+    streaming = {"k_measure_probs_s<true>", "k_measure_probs_s<false>", "k_collapse_s<true>", "k_collapse_s<false>",
+                 "k_insert_s<true>", "k_insert_s<false>", "k_permute_s", "k_diag_table_s"}
+    plain = {"k_measure_probs", "k_collapse", "k_insert", "k_permute", "k_diag_table"}
+    assert names == (streaming if variant == 0 else plain), names
 
 
 def test_permute_matches_reference_convention(golden):

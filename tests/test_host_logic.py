@@ -192,11 +192,12 @@ def test_product_package_does_not_import_the_oracle():
     assert not offenders, offenders
     for path in (REPO / "quantum_computations_amd" / "csrc").iterdir():
         assert "oracle" not in path.read_text().lower() or path.suffix not in (".hip", ".h"), path
-    # bench.py may use it only inside cpu_baseline()
+    # bench.py may use it only inside its CPU-baseline legs (cpu_baseline, numpy_restatement_baseline)
     src = (REPO / "bench.py").read_text()
     uses = [m.start() for m in re.finditer(r"from oracle|import oracle", src)]
-    body = src[src.index("def cpu_baseline"):src.index("def main")]
-    assert len(uses) == 1 and "from oracle import c_oracle" in body
+    legs = (src.index("# ---- CPU legs"), src.index("# ---- config 4"))
+    assert len(uses) == 2 and all(legs[0] < u < legs[1] for u in uses)
+    assert "from oracle import c_oracle" in src[legs[0]:legs[1]]
 
 
 def test_library_has_no_cpu_fallback_symbols():
@@ -205,3 +206,22 @@ def test_library_has_no_cpu_fallback_symbols():
     out = subprocess.run(["nm", "-D", "--undefined-only", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
     assert "hipLaunchKernel" in out or "hipModuleLaunchKernel" in out or "__hipPushCallConfiguration" in out
     assert "oracle_apply" not in out
+
+
+def test_loggers_live_under_the_references_hierarchy():
+    """Reference scripts silence ``logging.getLogger('simulators')`` (impact_.../grover.py:24); that must reach us."""
+    import logging
+
+    from quantum_computations_amd.cv_simulator import gate_abc, gates, simulator, utils
+    from quantum_computations_amd.gkp_simulator import gates as gkp_gates
+    names = {m.logger.name for m in (gate_abc, gates, simulator, utils, gkp_gates)}
+    assert names == {"simulators.cv_simulator.gate_abc", "simulators.cv_simulator.gates",
+                     "simulators.cv_simulator.simulator", "simulators.cv_simulator.utils",
+                     "simulators.gkp_simulator.gates"}
+    root = logging.getLogger("simulators")
+    before = root.level
+    try:
+        root.setLevel(logging.ERROR)
+        assert not simulator.logger.isEnabledFor(logging.INFO)
+    finally:
+        root.setLevel(before)
