@@ -90,6 +90,16 @@ def insert_qubit(state: np.ndarray, index: int, amplitudes: np.ndarray) -> np.nd
     return np.ascontiguousarray(grown).reshape(-1)
 
 
+def reduced_density(state: np.ndarray, kept: list[int]) -> np.ndarray:
+    """Reduced density matrix of the qubits ``kept`` of a ket: ``ket2dm`` (``numpy_quantum.py:110-113``) with every
+    other qubit summed out, ``kept[0]`` the most significant bit of both indices -- computed as X X^H for the
+    (2^k x 2^(n-k)) matrix X without forming the 2^n x 2^n matrix."""
+    n = num_qubits(state)
+    rest = [q for q in range(n) if q not in kept]
+    x = np.transpose(state.reshape((2,) * n), list(kept) + rest).reshape(1 << len(kept), -1)
+    return x @ x.conj().T
+
+
 def axis_rotation(theta: float, axis) -> np.ndarray:
     """``numpy_quantum.py:104-105``: ``cos(theta/2) I - i sin(theta/2) (a.sigma)``."""
     x = np.array([[0, 1], [1, 0]], dtype=complex)

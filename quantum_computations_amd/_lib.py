@@ -54,7 +54,7 @@ SIGNATURES: dict[str, list] = {
     "qsv_probabilities": [_state_p, _u64_p, C.c_int, _dbl_p],
     "qsv_inner": [_state_p, _state_p, _dbl_p, _dbl_p],
     "qsv_expect_pauli": [_state_p, C.c_int, _int_p, C.c_char_p, _dbl_p, _dbl_p],
-    "qsv_reduced_density": [_state_p, C.c_int, _int_p, _dbl_p],
+    "qsv_reduced_density": [_state_p, C.c_int, _int_p, C.c_void_p],
     "qsv_expect_density": [_state_p, _state_p, _dbl_p, _dbl_p],
     "qsv_sample": [_state_p, C.c_int, C.c_void_p, C.c_void_p],
     "qsv_create_qudit": [C.c_int, C.c_int, C.c_int, C.POINTER(_state_p)],

@@ -2022,8 +2022,10 @@ int qsvk_reduced_density(qsv_state *st, int k, const int *bits, double *rho_out)
         for (int c = 0; c < D; ++c) {
             double vr, vi;
             if (big) {
-                // tile pair p = (ti <= tj); D layout: col = lane & 15, row = (lane >> 4) + 4 reg
-                const bool upper = r / 16 <= c / 16;
+                // tile pair p = (ti <= tj); D layout: col = lane & 15, row = (lane >> 4) + 4 reg.  Entries below the
+                // diagonal are the conjugates of those above it and the diagonal is real, exactly (the matrix cores
+                // sum the two mirror entries of a diagonal tile in different orders: equal up to rounding only)
+                const bool upper = r <= c;
                 const int rr = upper ? r : c, cc = upper ? c : r;
                 const int ti = rr / 16, tj = cc / 16;
                 int pidx = 0;
@@ -2033,6 +2035,7 @@ int qsvk_reduced_density(qsv_state *st, int k, const int *bits, double *rho_out)
                 vr = raw[((pidx * 2 + 0) * 4 + reg) * 64 + lane];
                 vi = raw[((pidx * 2 + 1) * 4 + reg) * 64 + lane];
                 if (!upper) vi = -vi;  // rho[r][c] = conj(rho[c][r])
+                if (r == c) vi = 0.0;
             } else {
                 vr = raw[2 * (r * D + c)];
                 vi = raw[2 * (r * D + c) + 1];

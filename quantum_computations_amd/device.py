@@ -137,7 +137,7 @@ class DeviceState:
         _lib.call("qsv_upload", self._h, _ptr(buf), int(offset), buf.size)
 
     def copy(self) -> "DeviceState":
-        other = DeviceState.zeros(self.num_qubits, self.device)
+        other = DeviceState.zeros(DeviceState.num_qubits.fget(self), self.device)     # register qubits, whatever the view
         _lib.call("qsv_copy", other._h, self._h)
         return other
 

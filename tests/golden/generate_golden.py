@@ -233,6 +233,36 @@ def gen_measure_insert():
 
 
 # (6) the 3-qubit Grover anchor and the hand-decomposed CCZ ---------------------------------------------------
+def gen_readout():
+    """numpy_quantum.py:110-166: ket2dm, fidelity in its four branches, purity -- on seeded kets and mixed states; plus
+    reduced density matrices obtained from the reference's own ket2dm by summing out the other qubits."""
+    rng = np.random.default_rng(148)
+    cases, arrays = [], {}
+    for n in (2, 3, 5):
+        a, b = complex_ket(n, rng), complex_ket(n, rng)
+        mix = rng.random(3)
+        mix /= mix.sum()
+        kets = [complex_ket(n, rng) for _ in range(3)]
+        rho = sum(w * ref_npq.ket2dm(k) for w, k in zip(mix, kets))
+        sigma = 0.7 * ref_npq.ket2dm(a) + 0.3 * np.identity(1 << n) / (1 << n)
+        tag = f"n{n}"
+        arrays.update({f"{tag}_a": a, f"{tag}_b": b, f"{tag}_rho": rho, f"{tag}_sigma": sigma})
+        values = {"ket_ket": float(ref_npq.fidelity(a, b)), "ket_dm": float(ref_npq.fidelity(a, rho)),
+                  "dm_ket": float(ref_npq.fidelity(sigma, b)), "dm_dm": float(ref_npq.fidelity(rho, sigma)),
+                  "purity_rho": float(ref_npq.purity(rho)), "purity_sigma": float(ref_npq.purity(sigma)),
+                  "purity_pure": float(ref_npq.purity(ref_npq.ket2dm(a)))}
+        kept_sets = [[0], [n - 1], [1, 0]] + ([[2, 0, 4], [4, 3, 2, 1]] if n == 5 else [])
+        for kept in kept_sets:
+            full = ref_npq.ket2dm(a).reshape((2,) * (2 * n))
+            rest = [q for q in range(n) if q not in kept]
+            # rho_kept[i, j] = sum_rest full[i, rest, j, rest], kept[0] the most significant bit of i and j
+            sub = "".join(chr(97 + q) for q in range(n)) + "".join(chr(97 + q) if q in rest else chr(65 + q) for q in range(n))
+            out = "".join(chr(97 + q) for q in kept) + "".join(chr(65 + q) for q in kept)
+            arrays[f"{tag}_rdm_{'_'.join(map(str, kept))}"] = np.einsum(f"{sub}->{out}", full).reshape(1 << len(kept), -1)
+        cases.append({"n": n, "tag": tag, "values": values, "kept": kept_sets})
+    save("dv_readout.npz", cases=json.dumps(cases), **arrays)
+
+
 def gen_grover():
     arrays, cases = {}, []
     for tagged in ([3, 6], [0, 4], [2, 7]):
@@ -606,11 +636,15 @@ if __name__ == "__main__":
     if "--gkp-only" in sys.argv:
         gen_gkp()
         sys.exit(0)
+    if "--readout-only" in sys.argv:
+        gen_readout()
+        sys.exit(0)
     gen_single_gates()
     gen_expand_gate()
     gen_clifford()
     gen_random_circuits()
     gen_measure_insert()
+    gen_readout()
     gen_grover()
     gen_cv()
     gen_cv_extra()

@@ -387,6 +387,68 @@ def test_streaming_readout_kernels_every_position(variant):
     assert names == (streaming if variant == 0 else plain), names
 
 
+def test_reduced_density_matrices_and_density_registers(golden):
+    """f2: reduced density matrices in one read pass (k_rdm on the matrix cores from 14 qubits up, k_rdm_small below),
+    fidelity / purity with the operands in HBM, density matrices as device registers."""
+    from quantum_computations_amd.device import DensityState
+    from quantum_computations_amd.dv_simulator import numpy_quantum as npq
+    g = golden["dv_readout"]
+    for case in golden.cases("dv_readout"):                       # what the reference itself computed
+        tag, v = case["tag"], case["values"]
+        a, b, rho, sigma = (g[f"{tag}_{k}"] for k in ("a", "b", "rho", "sigma"))
+        da, db = DeviceState.from_numpy(a), DeviceState.from_numpy(b)
+        drho, dsigma = DensityState.from_numpy(rho), DensityState.from_numpy(sigma)
+        assert abs(npq.fidelity(da, db) - v["ket_ket"]) < 1e-13
+        assert abs(npq.fidelity(da, drho) - v["ket_dm"]) < 1e-13 and abs(npq.fidelity(a, drho) - v["ket_dm"]) < 1e-13
+        assert abs(npq.fidelity(dsigma, db) - v["dm_ket"]) < 1e-13 and abs(npq.fidelity(dsigma, b) - v["dm_ket"]) < 1e-13
+        assert abs(npq.fidelity(drho, dsigma) - v["dm_dm"]) < 1e-10
+        assert abs(npq.purity(drho) - v["purity_rho"]) < 1e-13 and abs(npq.purity(dsigma) - v["purity_sigma"]) < 1e-13
+        for kept in case["kept"]:
+            want = g[f"{tag}_rdm_{'_'.join(map(str, kept))}"]
+            assert maxdiff(da.reduced_density(kept), want) < 1e-14, (tag, kept)
+        assert da.last_kernel() == "k_rdm_small"
+    # registers large enough for the matrix-core kernel: every k, kept qubits anywhere, in any order
+    rng = np.random.default_rng(8)
+    for n in (14, 16):
+        ket = W.random_ket(n, 80 + n)
+        dev = DeviceState.from_numpy(ket)
+        for k in range(1, 7):
+            for trial in range(3):
+                kept = [int(q) for q in rng.choice(n, size=k, replace=False)]
+                if trial == 0:
+                    kept = list(range(n - k, n))                  # the lowest index bits: rows inside a cache line
+                elif trial == 1:
+                    kept = list(range(k))[::-1]                   # the top bits, reversed
+                got = dev.reduced_density(kept)
+                assert dev.last_kernel() == f"k_rdm<{1 if k <= 4 else 2 if k == 5 else 4}>"
+                assert maxdiff(got, O.reduced_density(ket, kept)) < 1e-14, (n, kept)
+                assert abs(np.trace(got).real - 1.0) < 1e-13 and maxdiff(got, got.conj().T) == 0.0
+        assert np.array_equal(dev.reduced_density([3, 1]), dev.reduced_density([3, 1]))      # deterministic sums
+    with pytest.raises(ValueError):
+        dev.reduced_density(list(range(7)))
+    with pytest.raises(ValueError):
+        dev.reduced_density([0, 0])
+    # a density matrix kept on the device through a circuit: U rho U^dagger gate by gate (gates.py:51-52)
+    n = 5
+    kets = [W.random_ket(n, s) for s in (1, 2)]
+    rho = 0.6 * npq.ket2dm(kets[0]) + 0.4 * npq.ket2dm(kets[1])
+    dev = DensityState.from_numpy(rho)
+    assert dev.ndim == 2 and dev.shape == (32, 32) and dev.num_qubits == n
+    ops = W.random_circuit(n, 30, 5)
+    out = dev
+    for gate in W.to_gates(ops):
+        out = gate.apply(out)
+        assert out is dev
+    want = 0.6 * npq.ket2dm(O.run_circuit(ops, kets[0])[0]) + 0.4 * npq.ket2dm(O.run_circuit(ops, kets[1])[0])
+    assert maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL
+    assert abs(dev.purity() - npq.purity(want)) < 1e-12
+    target = DeviceState.from_numpy(O.run_circuit(ops, kets[0])[0])
+    assert abs(npq.fidelity(target, dev) - npq.fidelity(O.run_circuit(ops, kets[0])[0], want)) < 1e-12
+    clone = dev.copy()
+    G.X(0).apply(clone)
+    assert isinstance(clone, DensityState) and maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL
+
+
 def test_permute_matches_reference_convention(golden):
     g = golden["dv_expand_gate"]
     for case in golden.cases("dv_expand_gate"):

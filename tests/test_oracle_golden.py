@@ -203,3 +203,22 @@ def test_c_oracle_dense_matvec_is_the_literal_algorithm(golden):
     ket = g["perm_in"]
     assert np.max(np.abs(c_oracle.dense_matvec(full, ket) - full @ ket)) < TOL
     assert np.max(np.abs(c_oracle.dense_matvec(full, ket) - O.apply_gate(ket, g["u4"], [3, 1]))) < TOL
+
+
+def test_readout_functions_match_the_reference(golden):
+    """ket2dm / fidelity (all four branches) / purity of numpy_quantum.py:110-166 as the reference evaluated them, and
+    reduced density matrices derived from its ket2dm: pins the package's host mirror and the oracle's reduced_density."""
+    from quantum_computations_amd.dv_simulator import numpy_quantum as npq
+    g = golden["dv_readout"]
+    for case in golden.cases("dv_readout"):
+        tag, v = case["tag"], case["values"]
+        a, b, rho, sigma = (g[f"{tag}_{k}"] for k in ("a", "b", "rho", "sigma"))
+        assert abs(npq.fidelity(a, b) - v["ket_ket"]) < 1e-14
+        assert abs(npq.fidelity(a, rho) - v["ket_dm"]) < 1e-14
+        assert abs(npq.fidelity(sigma, b) - v["dm_ket"]) < 1e-14
+        assert abs(npq.fidelity(rho, sigma) - v["dm_dm"]) < 1e-10
+        assert abs(npq.purity(rho) - v["purity_rho"]) < 1e-14 and abs(npq.purity(sigma) - v["purity_sigma"]) < 1e-14
+        assert abs(npq.purity(npq.ket2dm(a)) - v["purity_pure"]) < 1e-14
+        for kept in case["kept"]:
+            want = g[f"{tag}_rdm_{'_'.join(map(str, kept))}"]
+            assert np.max(np.abs(O.reduced_density(a, kept) - want)) < 1e-14, (tag, kept)
