@@ -185,6 +185,36 @@ def run_cfg4(steps=1, n_modes=6, d=32, gates=60):
     return out
 
 
+def run_cfg5_single_gpu(n=30, iterations=2):
+    """The one-GPU form of BASELINE.json configs[4]: Grover search on n = 30 qubits (16 GiB), success probability
+    against sin^2((2k + 1) asin 2^(-n/2)).  (The configuration itself shards n = 30 over 8 GPUs: --config cfg5.)"""
+    from quantum_computations_amd import workloads as W
+    from quantum_computations_amd.device import DeviceState
+    from quantum_computations_amd.dv_simulator import gates as G
+
+    marked = (0b1011001110001111 << max(0, n - 16)) % (1 << n) | 1
+    dev = DeviceState.zeros(n)
+    h = G.H(0).matrix
+    for q in range(n):
+        dev.apply_matrix(h, [q])
+    dev.sync()
+    t0 = time.perf_counter()
+    for _ in range(iterations):
+        W.grover_iteration(dev, n, marked)
+    dev.sync()
+    dt = time.perf_counter() - t0
+    p = float(dev.probabilities([marked])[0])
+    want = W.grover_success_probability(n, iterations)
+    gates = iterations * W.grover_gate_count(n, marked)
+    out = {"workload": f"Grover search, n={n} ({16 * (1 << n) / 2**30:.0f} GiB on one GPU), {iterations} iterations, "
+                       f"{gates} gates (BASELINE.json configs[4] shards this register over 8 GPUs)",
+           "gate_apps_per_sec": gates / dt, "equiv_28_qubit_gate_apps_per_sec": gates / dt * 2.0 ** (n - 28),
+           "algorithmic_GBps": 2 * 16 * (1 << n) * gates / dt / 1e9, "success_probability": p, "analytic": want,
+           "rel_err": abs(p - want) / want, "norm2": dev.norm2()}
+    dev.close()
+    return out
+
+
 # ---- circuits of the sharded configurations -------------------------------------------------------------------------
 def remote_cx_pairs(n, g):
     """32 CX gates whose (control, target) cycle through global->local, local->global and global->global pairs."""
@@ -257,7 +287,8 @@ def main():
     else:
         marked = (0b1011001110001111 << max(0, n - 16)) % (1 << n) | 1
         iterations = 8
-        gates, gates_per_step = None, iterations * W.grover_gate_count(n, marked)
+        gates = W.grover_circuit(n, marked, iterations)
+        gates_per_step = len(gates)
         workload = (f"Grover search on {n} qubits over {world} GPU(s), {iterations} iterations per step, one marked "
                     f"item (BASELINE.json configs[4])")
 
@@ -317,34 +348,44 @@ def main():
         for q in range(n):
             dev.apply_matrix(h, [q])
 
+    trace = []                                   # N > 1, rank 0: (kernel, launch was purely local) per recorded gate
+    passes = [0]                                 # passes of the circuit applied so far (Grover: iterations / 8)
+
     def step(record: bool, slot0: int = 0):
-        slot = slot0
-        if gates is None:                        # cfg5: the Grover iterations drive the register directly
-            for _ in range(iterations):
-                W.grover_iteration(dev, n, marked)
-            return slot
-        if world > 1:
-            dev.prepare(gates)       # what Simulator.run does: lets the shards plan which qubits to give up
-        for gate in gates:
+        slot = [slot0]
+
+        def apply(gate):
             if record:
-                dev.event_record(slot)
+                before = (dev.exchanges, dev.local_swaps) if world > 1 else None
+                dev.event_record(slot[0])
             gate.apply(dev)
             if record:
-                dev.event_record(slot + 1)
-            slot += 2
-        return slot
+                dev.event_record(slot[0] + 1)
+                if world > 1:                    # the shards' kernels depend on the layout: ask after every launch
+                    trace.append((dev.last_kernel(), before == (dev.exchanges, dev.local_swaps)))
+            slot[0] += 2
+
+        if world > 1:
+            # what Simulator.run does on a sharded register: announce the circuit (the shards plan which qubits to
+            # give up) and take commuting gates local-first
+            dev.run_circuit(gates, apply)
+        else:
+            for gate in gates:
+                apply(gate)
+        passes[0] += 1
+        return slot[0]
 
     # which kernel each gate of the circuit lands in (asked of the library, not guessed)
     kernels = []
-    if world == 1 and gates is not None:
+    if world == 1:
         for gate in gates:
             gate.apply(dev)
             kernels.append(dev.last_kernel())
+        passes[0] += 1
     for _ in range(args.warmup):
         step(False)
     # the event ring holds 16384 marks
-    recorded_steps = min(args.steps, 16000 // (2 * len(gates))) if world == 1 and gates is not None else 0
-    grover_done = (args.warmup * iterations) if args.config == "cfg5" else 0
+    recorded_steps = min(args.steps, 16000 // (2 * len(gates)))
     barrier()
     torch.cuda.synchronize()
     dev.sync()
@@ -359,7 +400,7 @@ def main():
 
     extra = {}
     if args.config == "cfg5":                    # all ranks take part in the read-out
-        total_iterations = grover_done + args.steps * iterations
+        total_iterations = passes[0] * iterations
         p = float(dev.probabilities([marked])[0])
         want = W.grover_success_probability(n, total_iterations)
         extra["grover"] = {"iterations_applied": total_iterations, "success_probability": p, "analytic": want,
@@ -405,10 +446,17 @@ def main():
             "messages_per_circuit": dev.messages / passes, "piece_GiB": min(dev.chunk_amps, 1 << n_local) * 16 / 2**30}
     if recorded_steps:
         per_kernel = {}
-        for s in range(recorded_steps):
-            for i, c in enumerate(kernels):
-                a = 2 * (s * len(gates) + i)
-                per_kernel.setdefault(c, []).append(dev.event_elapsed_ms(a, a + 1))
+        if world == 1:
+            for s in range(recorded_steps):
+                for i, c in enumerate(kernels):
+                    a = 2 * (s * len(gates) + i)
+                    per_kernel.setdefault(c, []).append(dev.event_elapsed_ms(a, a + 1))
+        else:       # this rank's launches that moved nothing between GPUs (SWAPs relabel the map and launch nothing)
+            last = None
+            for i, (c, local) in enumerate(trace):
+                if local and c and c != "oracle-engine" and not (c == last and dev.event_elapsed_ms(2 * i, 2 * i + 1) < 1e-3):
+                    per_kernel.setdefault(c, []).append(dev.event_elapsed_ms(2 * i, 2 * i + 1))
+                last = c
         # dominant kernel = the full-traffic dense instantiation with the most device time
         full = {k: v for k, v in per_kernel.items() if k.startswith("k_dense<")} or per_kernel
         dominant = max(full, key=lambda k: sum(full[k]))
@@ -421,6 +469,7 @@ def main():
             if entry:
                 traffic, traffic_src = entry["hbm_bytes_per_launch"], entry["source"]
         result["roofline"] = {
+            **({"scope": "rank 0's launches of its dominant kernel, exchanges excluded"} if world > 1 else {}),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": dominant, "algorithmic_bytes_per_launch": bytes_per_gate_per_gpu,
@@ -467,7 +516,7 @@ def main():
     if args.config == "cfg2" and world == 1 and not args.no_secondary:
         dev.close()
         del cpu_ket
-        secondary = {"cfg4": run_cfg4()}
+        secondary = {"cfg4": run_cfg4(), "cfg5_single_gpu": run_cfg5_single_gpu()}
         if not args.no_cpu_baseline:
             secondary["cpu_numpy_restatement_n28"] = numpy_restatement_baseline(ops, n, STATE_SEED)
             secondary["cpu_literal_dense_algorithm_n12"] = literal_dense_baseline()
@@ -511,10 +560,7 @@ def rehearse(args, world, rank, n, gates, workload):
     if world > 1:
         dist.init_process_group("gloo")
     plan = ShardedState.plan_only(n, world)
-    if gates is not None:
-        plan.prepare(gates)
-        for gate in gates:
-            gate.apply(plan)
+    plan.run_circuit(gates)
     mine = torch.tensor([plan.exchanges, plan.qubits_exchanged, plan.bytes_sent], dtype=torch.int64)
     agree = True
     if world > 1:

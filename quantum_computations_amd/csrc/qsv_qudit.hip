@@ -171,9 +171,13 @@ constexpr int MAX_BLOCK = 32;
 // flight and short dependency chains.  Workgroup order: all blocks of one group of planes are dealt to the same XCD
 // back to back, so when the plane group is not contiguous in memory (R < 8: neighbouring lanes are up to 16 KiB apart and
 // every 128-byte line is shared by several anti-diagonals) the re-touched lines are served by that XCD's L2.
+// Blocks come in pairs (`pairs`: a large block with a small one, at most MAX_BLOCK elements together, second = -1 if
+// alone) that one workgroup handles one after the other: a beam splitter's 63 anti-diagonals of 1..32 elements become 32
+// work items of exactly 32 elements each, instead of 63 whose smallest move 16 bytes per thread.
 template <int THREADS, bool REALM>
 __global__ __launch_bounds__(THREADS) void k_mode2_blocks(amp_t *__restrict__ a, uint64_t L, int d, uint64_t Mid,
-                                                         uint64_t R, int nblocks, uint64_t groups,
+                                                         uint64_t R, int nblocks /* pairs */, uint64_t groups,
+                                                         const int32_t *__restrict__ pairs,
                                                          const int32_t *__restrict__ sizes,
                                                          const int64_t *__restrict__ mat_start,  // in complex entries
                                                          const int32_t *__restrict__ idx_start,
@@ -185,12 +189,15 @@ __global__ __launch_bounds__(THREADS) void k_mode2_blocks(amp_t *__restrict__ a,
         // workgroup w runs on XCD w % 8; its sequence number there selects (group, block), block fastest
         const uint64_t seq = w / 8;
         const uint64_t g = (seq / nblocks) * 8 + w % 8;
-        const int b = static_cast<int>(seq % nblocks);
+        const int item = static_cast<int>(seq % nblocks);
         if (g >= groups) continue;
         const uint64_t p = g * THREADS + threadIdx.x;
         if (p >= planes) continue;
         const uint64_t r = p % R, m = (p / R) % Mid, l = p / (R * Mid);
         amp_t *base = a + l * (R * d * Mid * d) + m * (R * d) + r;
+        for (int half = 0; half < 2; ++half) {
+        const int b = pairs[2 * item + half];
+        if (b < 0) continue;
         const int s = sizes[b];
         const uint64_t *off = plane_off + idx_start[b];
         const double *M = mats + (REALM ? 1 : 2) * mat_start[b];  // real matrices are stored as one double per entry
@@ -216,6 +223,7 @@ __global__ __launch_bounds__(THREADS) void k_mode2_blocks(amp_t *__restrict__ a,
                 }
             if (THREADS == QSV_BLOCK) __builtin_nontemporal_store(acc, base + off[row]);
             else base[off[row]] = acc;
+        }
         }
     }
 }
@@ -652,11 +660,23 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
         real_mats.resize(mtot);
         for (int64_t i = 0; i < mtot; ++i) real_mats[i] = mats[2 * i];
     }
-    // one device buffer: [mats | plane_off | mat_start | sizes | idx_start], every section 16-byte aligned
+    // pair blocks: largest with the smallest that still fits MAX_BLOCK elements together
+    std::vector<int> order(nblocks);
+    for (int k = 0; k < nblocks; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sizes[x] > sizes[y]; });
+    std::vector<int32_t> pairs;
+    for (int lo = 0, hi = nblocks - 1; lo <= hi; ++lo) {
+        pairs.push_back(order[lo]);
+        if (lo < hi && sizes[order[lo]] + sizes[order[hi]] <= MAX_BLOCK) pairs.push_back(order[hi--]);
+        else pairs.push_back(-1);
+    }
+    const int nitems = static_cast<int>(pairs.size() / 2);
+    // one device buffer: [mats | plane_off | mat_start | sizes | idx_start | pairs], every section 16-byte aligned
     auto pad16 = [](size_t x) { return (x + 15) / 16 * 16; };
     const size_t b_m = pad16(sizeof(double) * 2 * mtot), b_o = pad16(sizeof(uint64_t) * off.size()),
                  b_s = pad16(sizeof(int64_t) * nblocks), b_z = pad16(sizeof(int32_t) * nblocks);
-    int rc = qsvk_ensure_matrix(st, b_m + b_o + b_s + 2 * b_z);
+    const size_t b_p = pad16(sizeof(int32_t) * pairs.size());
+    int rc = qsvk_ensure_matrix(st, b_m + b_o + b_s + 2 * b_z + b_p);
     if (rc) return rc;
     char *p = reinterpret_cast<char *>(st->dev_matrix);
     double *d_m = reinterpret_cast<double *>(p);
@@ -664,12 +684,14 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
     int64_t *d_s = reinterpret_cast<int64_t *>(p + b_m + b_o);
     int32_t *d_z = reinterpret_cast<int32_t *>(p + b_m + b_o + b_s);
     int32_t *d_i = reinterpret_cast<int32_t *>(p + b_m + b_o + b_s + b_z);
+    int32_t *d_p = reinterpret_cast<int32_t *>(p + b_m + b_o + b_s + 2 * b_z);
     if (real) QSV_HIP(hipMemcpyAsync(d_m, real_mats.data(), sizeof(double) * mtot, hipMemcpyHostToDevice, st->stream));
     else QSV_HIP(hipMemcpyAsync(d_m, mats, sizeof(double) * 2 * mtot, hipMemcpyHostToDevice, st->stream));
     QSV_HIP(hipMemcpyAsync(d_o, off.data(), sizeof(uint64_t) * off.size(), hipMemcpyHostToDevice, st->stream));
     QSV_HIP(hipMemcpyAsync(d_s, mat_start.data(), sizeof(int64_t) * nblocks, hipMemcpyHostToDevice, st->stream));
     QSV_HIP(hipMemcpyAsync(d_z, sizes, sizeof(int32_t) * nblocks, hipMemcpyHostToDevice, st->stream));
     QSV_HIP(hipMemcpyAsync(d_i, idx_start.data(), sizeof(int32_t) * nblocks, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipMemcpyAsync(d_p, pairs.data(), sizeof(int32_t) * pairs.size(), hipMemcpyHostToDevice, st->stream));
     QSV_HIP(hipStreamSynchronize(st->stream));  // all sources are pageable host memory that dies at return
     const uint64_t planes = L * Mid * R;
     // R >= 8: a 128-byte line holds amplitudes of one plane point only, so every line is touched by exactly one block
@@ -677,23 +699,23 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
     // group (64 planes) small enough for the XCD's L2 to serve the re-touched lines.
     const int threads = R >= 8 ? QSV_BLOCK : 64;
     const uint64_t groups = (planes + threads - 1) / threads;
-    const uint64_t items = (groups + 7) / 8 * 8 * nblocks;
+    const uint64_t items = (groups + 7) / 8 * 8 * nitems;
     const unsigned grid = static_cast<unsigned>(items < 0x00ffffffull ? items : 0x00ffffffull);
     snprintf(st->last_kernel, sizeof(st->last_kernel), "k_mode2_blocks<%d, %s>", threads, real ? "true" : "false");
     if (threads == QSV_BLOCK) {
         if (real)
             hipLaunchKernelGGL((k_mode2_blocks<QSV_BLOCK, true>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, L,
-                               static_cast<int>(d), Mid, R, nblocks, groups, d_z, d_s, d_i, d_o, d_m);
+                               static_cast<int>(d), Mid, R, nitems, groups, d_p, d_z, d_s, d_i, d_o, d_m);
         else
             hipLaunchKernelGGL((k_mode2_blocks<QSV_BLOCK, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, L,
-                               static_cast<int>(d), Mid, R, nblocks, groups, d_z, d_s, d_i, d_o, d_m);
+                               static_cast<int>(d), Mid, R, nitems, groups, d_p, d_z, d_s, d_i, d_o, d_m);
     } else {
         if (real)
             hipLaunchKernelGGL((k_mode2_blocks<64, true>), dim3(grid), dim3(64), 0, st->stream, st->data, L,
-                               static_cast<int>(d), Mid, R, nblocks, groups, d_z, d_s, d_i, d_o, d_m);
+                               static_cast<int>(d), Mid, R, nitems, groups, d_p, d_z, d_s, d_i, d_o, d_m);
         else
             hipLaunchKernelGGL((k_mode2_blocks<64, false>), dim3(grid), dim3(64), 0, st->stream, st->data, L,
-                               static_cast<int>(d), Mid, R, nblocks, groups, d_z, d_s, d_i, d_o, d_m);
+                               static_cast<int>(d), Mid, R, nitems, groups, d_p, d_z, d_s, d_i, d_o, d_m);
     }
     return check_launch();
 }

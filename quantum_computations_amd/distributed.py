@@ -125,7 +125,8 @@ class ShardedState:
         self.messages = 0                                 # point-to-point messages this rank sent
         self.local_swaps = 0                              # local passes spent lining victims up for an exchange
         self._plan = None                                 # look-ahead set by prepare(): [(indices, mixing qubits)]
-        self._cursor = 0
+        self._cursor = 0                                  # first plan entry not applied yet
+        self._done = []                                   # plan entries already applied (they may arrive out of order)
 
     # ---- construction ---------------------------------------------------------------------------
     @classmethod
@@ -329,39 +330,124 @@ class ShardedState:
             self.phys[i_slot], self.phys[i_g] = gb, slot
 
     # ---- look-ahead: which local qubits to give up --------------------------------------------------
+    @staticmethod
+    def mixing_qubits(gate) -> frozenset | None:
+        """The qubits ``gate`` does not conserve (those must be local when it runs); ``None`` for gates that change
+        the register size or have no square matrix.  Objects may state theirs in a ``mixing`` attribute (a
+        multi-controlled phase mixes nothing); the answer is cached on the gate."""
+        inner = getattr(gate, "gate", gate)                         # ClassicalControl wraps a gate
+        cached = getattr(inner, "_qsv_mixing", None)
+        if cached is not None:
+            return cached
+        explicit = getattr(inner, "mixing", None)
+        if explicit is not None:
+            mixing = frozenset(explicit)
+        else:
+            matrix, indices = getattr(inner, "matrix", None), list(getattr(inner, "indices", []))
+            if matrix is None or np.asarray(matrix).shape[0] != np.asarray(matrix).shape[1]:
+                return None
+            m = np.asarray(matrix, dtype=np.complex128)
+            k = len(indices)
+            if k == 2 and np.array_equal(m, _SWAP):
+                mixing = frozenset()                                 # a relabelling of the qubit map
+            else:
+                mixing = frozenset(q for j, q in enumerate(indices) if not _leg_is_block_diagonal(m, k, j))
+        try:
+            inner._qsv_mixing = mixing
+        except AttributeError:
+            pass
+        return mixing
+
     def prepare(self, circuit) -> None:
         """Tell the register which gates are about to be applied (objects with ``indices`` / ``matrix``, in order).
 
         With the plan, an exchange evicts the local qubits whose next *mixing* use lies farthest ahead (Belady's
         rule) instead of whichever qubits sit on the top local bits, which cuts the number of exchanges of a random
         circuit several-fold.  Purely an optimisation: every rank computes the same plan from the same
-        circuit, a gate that does not match the plan simply switches the look-ahead off, and the plan stops at the
-        first measurement / insertion (they renumber the qubits)."""
+        circuit, gates may arrive in a different order as long as they are the announced ones (``run_circuit`` applies
+        commuting gates local-first), a gate that is not in the plan simply switches the look-ahead off, and the plan
+        stops at the first measurement / insertion (they renumber the qubits)."""
         plan = []
         for gate in circuit:
-            inner = getattr(gate, "gate", gate)                     # ClassicalControl wraps a gate
-            matrix, indices = getattr(inner, "matrix", None), list(getattr(inner, "indices", []))
-            if matrix is None or np.asarray(matrix).shape[0] != np.asarray(matrix).shape[1]:
+            mixing = self.mixing_qubits(gate)
+            if mixing is None:
                 break
-            m = np.asarray(matrix, dtype=np.complex128)
-            k = len(indices)
-            mixing = frozenset(q for j, q in enumerate(indices) if not _leg_is_block_diagonal(m, k, j))
-            plan.append((tuple(indices), mixing))
-        self._plan, self._cursor = plan, 0
+            inner = getattr(gate, "gate", gate)
+            indices = tuple(int(q) for q in inner.indices)
+            matrix = getattr(inner, "matrix", None)
+            relabel = len(indices) == 2 and matrix is not None and np.array_equal(np.asarray(matrix), _SWAP)
+            plan.append((indices, mixing, relabel))
+        self._plan, self._cursor, self._done = plan, 0, [False] * len(plan)
+
+    PLAN_WINDOW = 512      # how far ahead of the first pending entry an announced gate may arrive
 
     def _advance_plan(self, indices) -> None:
         if self._plan is None:
             return
-        if self._cursor >= len(self._plan) or self._plan[self._cursor][0] != tuple(indices):
-            self._plan = None                                        # the caller left the announced circuit
-            return
-        self._cursor += 1
+        want = tuple(int(q) for q in indices)
+        for step in range(self._cursor, min(len(self._plan), self._cursor + self.PLAN_WINDOW)):
+            if not self._done[step] and self._plan[step][0] == want:
+                self._done[step] = True
+                while self._cursor < len(self._plan) and self._done[self._cursor]:
+                    self._cursor += 1
+                return
+        self._plan = None                                            # the caller left the announced circuit
 
     def _next_mixing_use(self, qubit: int) -> int:
+        """First pending plan step that mixes the data now known as ``qubit`` (SWAPs ahead rename it on the way)."""
         for step in range(self._cursor, len(self._plan)):
-            if qubit in self._plan[step][1]:
+            if self._done[step]:
+                continue
+            indices, mixing, relabel = self._plan[step]
+            if relabel:
+                if qubit == indices[0]:
+                    qubit = indices[1]
+                elif qubit == indices[1]:
+                    qubit = indices[0]
+            elif qubit in mixing:
                 return step
         return 1 << 60
+
+    def needs_exchange(self, gate) -> bool:
+        """Would applying ``gate`` now move data between GPUs?  (Same answer on every rank: layout only.)"""
+        mixing = self.mixing_qubits(gate)
+        if mixing is None:
+            inner = getattr(gate, "gate", gate)
+            mixing = frozenset(getattr(inner, "indices", []))        # measurement / unknown: its qubits must be local
+            if getattr(inner, "matrix", None) is not None and np.asarray(inner.matrix).shape[0] == 1:
+                return False                                         # Insert: never any traffic
+        return any(0 <= q < self.n and self._bit(q) >= self.n_local for q in mixing)
+
+    def run_circuit(self, circuit, apply=None) -> list:
+        """Apply ``circuit`` with commuting gates reordered local-first: of the leading gates that act on pairwise
+        disjoint qubits (they commute), one that needs no exchange goes first; only when every one of them mixes a
+        remote qubit does the first take its exchange -- by then the qubits that leave have had their gates of this
+        layer.  A layer of one-qubit gates on all n qubits (Grover's H and X walls) then costs one exchange instead
+        of one per remote qubit per wall.  Returns the gates in the order applied; ``apply(gate)`` does the
+        application (default ``gate.apply(self)``) and may return False to say the gate was skipped."""
+        pending = list(circuit)
+        self.prepare(pending)
+        order = []
+        while pending:
+            pick, used = 0, set()
+            for j, gate in enumerate(pending[:256]):
+                inner = getattr(gate, "gate", gate)
+                if inner is not gate or self.mixing_qubits(gate) is None:
+                    break                                            # barriers are taken only from the front
+                qs = set(inner.indices)
+                if qs & used:
+                    break
+                used |= qs
+                if not self.needs_exchange(gate):
+                    pick = j
+                    break
+            gate = pending.pop(pick)
+            order.append(gate)
+            if apply is not None:
+                apply(gate)
+            else:
+                gate.apply(self)
+        return order
 
     def _choose_victims(self, count: int, avoid: set[int]) -> list[int]:
         """``count`` local bits whose qubits leave the shard, never one of ``avoid``."""

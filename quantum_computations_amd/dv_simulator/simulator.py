@@ -72,22 +72,30 @@ class Simulator:
             self.launch_list = fuse_circuit(self.circuit, self._fuse, n_qubits=dev.num_qubits, remote=remote)
         else:
             self.launch_list = self.circuit
-        if hasattr(dev, "prepare"):
-            dev.prepare(self.launch_list)     # sharded registers plan their qubit exchanges over the whole circuit
-        for gate in self.launch_list:
+        box = [dev]
+
+        def apply(gate) -> None:
             if isinstance(gate, ClassicalControl):
                 if not gate.eval(self.results):
-                    continue
+                    return
                 gate = gate.gate
             if on_host:
                 for source in getattr(gate, "sources", [gate]):
-                    operands.append(_dtype_witness(source, dev.num_qubits))
-            output = gate.apply(dev)
+                    operands.append(_dtype_witness(source, box[0].num_qubits))
+            output = gate.apply(box[0])
             if isinstance(output, tuple):
-                dev = output[0]
+                box[0] = output[0]
                 self.results.append(output[1])
             else:
-                dev = output
+                box[0] = output
+
+        if hasattr(dev, "run_circuit"):
+            # sharded registers plan their qubit exchanges over the whole circuit and take commuting gates local-first
+            self.launch_list = dev.run_circuit(self.launch_list, apply)
+        else:
+            for gate in self.launch_list:
+                apply(gate)
+        dev = box[0]
         if not on_host:
             return dev
         final = dev.to_numpy()

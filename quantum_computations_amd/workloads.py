@@ -115,6 +115,42 @@ def random_ket(n: int, seed: int, chunk_bits: int = 24) -> np.ndarray:
 
 
 # ---- n-qubit Grover (cfg5).  Build-defined generalisation: the reference only has the 3-qubit circuit below ----
+class MCPhase:
+    """Multiply the amplitudes whose ``qubits`` are all 1 by ``phase`` (a multi-controlled Z for phase = -1), as an
+    object with the gate protocol (``indices``, ``apply``) so that circuits containing it can be announced to a sharded
+    register.  It conserves every qubit it touches: ``mixing`` is empty, it never moves data between GPUs."""
+
+    matrix = None
+    mixing = frozenset()
+
+    def __init__(self, qubits, phase: complex = -1.0):
+        self.indices = [int(q) for q in qubits]
+        self.phase = complex(phase)
+
+    def __repr__(self):
+        return f"MCPhase_{len(self.indices)}({self.phase})"
+
+    def apply(self, state):
+        if hasattr(state, "apply_mcphase"):
+            return state.apply_mcphase(self.indices, self.phase)
+        from .device import DeviceState
+        dev = DeviceState.from_numpy(np.asarray(state))
+        dev.apply_mcphase(self.indices, self.phase)
+        out = dev.to_numpy()
+        dev.close()
+        return out
+
+
+def grover_circuit(n: int, marked: int, iterations: int) -> list:
+    """``iterations`` Grover iterations as a gate list (what ``grover_iteration`` applies, in the same order)."""
+    zeros = [q for q in range(n) if not (marked >> (n - 1 - q)) & 1]
+    one = [G.X(q) for q in zeros] + [MCPhase(range(n))] + [G.X(q) for q in zeros]
+    one += [G.H(q) for q in range(n)] + [G.X(q) for q in range(n)] + [MCPhase(range(n))]
+    one += [G.X(q) for q in range(n)] + [G.H(q) for q in range(n)]
+    return [g for _ in range(iterations) for g in one]
+
+
+
 def grover_iteration(state, n: int, marked: int) -> None:
     """One Grover iteration on a device register (``DeviceState`` / ``ShardedState``): phase oracle on the basis
     state ``marked`` (X on its zero bits, multi-controlled Z, X back) followed by the diffuser H X (MCZ) X H.

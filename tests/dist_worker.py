@@ -111,9 +111,10 @@ def main():
             link[policy, planned] = st.link_bytes
             dry = ShardedState.plan_only(n, world, policy)   # the data-free schedule agrees with what really ran
             if planned:
-                dry.prepare(gates)
-            for gate in gates:
-                gate.apply(dry)
+                dry.run_circuit(gates)
+            else:
+                for gate in gates:
+                    gate.apply(dry)
             assert (dry.exchanges, dry.bytes_sent, dry.phys) == (st.exchanges, st.bytes_sent, st.phys)
         assert counts[policy, True] <= counts[policy, False], counts
     # round 1 routed every pairwise swap over all links in two all_to_all phases: 2 (G-1)/G half shards on the wire
@@ -124,12 +125,19 @@ def main():
         assert sent["auto", True] < relay * sent["pairwise", True], sent     # bytes on the wire vs round 1's scheme
     counts = {False: counts["auto", False], True: counts["auto", True], "pairwise": counts["pairwise", True]}
     sent = {"auto": sent["auto", True], "pairwise": sent["pairwise", True], "round1": int(relay * sent["pairwise", True])}
-    # a gate outside the announced circuit only switches the look-ahead off
+    # a gate outside the announced circuit only switches the look-ahead off (announced gates may come in any order)
     st = make_state(n, ket, args.backend, device)
     st.prepare(W.to_gates(ops))
-    G.H(n - 1).apply(st)
+    ccz = np.diag([1, 1, 1, 1, 1, 1, 1, -1]).astype(complex)
+    G.Gate([n - 1, 0, 2], ccz).apply(st)                     # no three-qubit gate was announced
     assert st._plan is None
-    check("off-plan gate", st.to_numpy(), O.apply_gate(ket, G.H(0).matrix, [n - 1]))
+    check("off-plan gate", st.to_numpy(), O.apply_gate(ket, ccz, [n - 1, 0, 2]))
+    st = make_state(n, ket, args.backend, device)
+    gates = W.to_gates(ops)
+    st.prepare(gates)
+    for gate in gates[1::2] + gates[0::2]:                    # every announced gate, in another order
+        st._advance_plan(gate.indices)
+    assert st._plan is not None and st._cursor == len(gates)
 
     # 2. the remote-qubit CX mix of BASELINE config 3: global->local, local->global, global->global
     ket = W.random_ket(n, 3)
@@ -259,6 +267,20 @@ def main():
     assert abs(p - want_p) < 1e-12, (p, want_p)
     assert abs(st.norm2() - 1.0) < 1e-12
 
+    # 3c. the same search as an announced gate list: walls of H and X on every qubit are taken local-first, so a wall
+    # costs one exchange (if any) instead of one per remote qubit; same probabilities, fewer exchange steps
+    direct_steps = st.exchanges
+    st = make_state(n, start, args.backend, device)
+    circuit = [G.H(q) for q in range(n)] + W.grover_circuit(n, marked, iterations)
+    out = Simulator(circuit).run(st)
+    assert out is st and abs(float(st.probabilities([marked])[0]) - want_p) < 1e-12
+    assert st.exchanges < direct_steps, (st.exchanges, direct_steps)
+    grover_steps = (direct_steps, st.exchanges)
+    fused = Simulator(circuit, fuse=2).run(make_state(n, start, args.backend, device))     # X H X per qubit in one launch
+    assert abs(float(fused.probabilities([marked])[0]) - want_p) < 1e-12
+    from quantum_computations_amd.fusion import fuse_circuit
+    assert len(circuit) > 2 * len(fuse_circuit(circuit, 2))
+
     # 4. counter-based fill: the sharded register equals the unsharded one
     if args.backend == "gloo":
         import oracle_engine
@@ -272,7 +294,8 @@ def main():
         print(f"dist_worker ok: world={world} backend={args.backend} n={n} chunk_amps={st.chunk_amps} "
               f"cx_exchanges={exchanges_cx} exchange_steps_120_gates no-plan={counts[False]} look-ahead={counts[True]} "
               f"pairwise={counts['pairwise']} bytes_sent_per_rank auto={sent['auto']} pairwise_direct={sent['pairwise']} "
-              f"pairwise_over_all_links(round 1)={sent['round1']}")
+              f"pairwise_over_all_links(round 1)={sent['round1']} grover_exchange_steps direct={grover_steps[0]} "
+              f"announced={grover_steps[1]}")
     dist.destroy_process_group()
 
 
