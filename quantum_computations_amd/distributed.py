@@ -680,6 +680,45 @@ class ShardedState:
             out[where] = self.local.probabilities(mine)
         return np.array(self._allreduce_sum(out.tolist()), dtype=np.float64)
 
+    def reduced_density(self, qubits) -> np.ndarray:
+        """Reduced density matrix of ``qubits`` (at most six), on every rank: the kept qubits are made local (the
+        trace over the rank bits is then a plain sum of the shards' matrices: one small all-reduce)."""
+        qubits = [int(q) for q in qubits]
+        if len(set(qubits)) != len(qubits):
+            raise ValueError("Indices must be distinct.")
+        for q in qubits:
+            self._bit(q)
+        self._localise_all(qubits, [])
+        rho = self.local.reduced_density([self._local_qubit(self._bit(q)) for q in qubits])
+        flat = self._allreduce_sum(np.concatenate([rho.real.ravel(), rho.imag.ravel()]).tolist())
+        half = len(flat) // 2
+        return (np.array(flat[:half]) + 1j * np.array(flat[half:])).reshape(rho.shape)
+
+    def expect_pauli(self, paulis: str, qubits) -> complex:
+        """``<psi| P |psi>`` for a Pauli string: X and Y legs are made local (they pair amplitudes), a Z on a rank bit
+        is this rank's sign."""
+        qubits = [int(q) for q in qubits]
+        if len(paulis) != len(qubits):
+            raise ValueError("one Pauli letter per qubit")
+        for q in qubits:
+            self._bit(q)
+        flipping = [q for q, p in zip(qubits, paulis) if p in "XY"]
+        self._localise_all(flipping, [q for q in qubits if q not in flipping])
+        sign, letters, local = 1.0, [], []
+        for q, p in zip(qubits, paulis):
+            b = self._bit(q)
+            if b >= self.n_local:
+                if p == "Z" and self._rank_bit(b):
+                    sign = -sign
+                elif p not in "IZ":
+                    raise ValueError(f"unknown Pauli letter {p!r}")
+            else:
+                letters.append(p)
+                local.append(self._local_qubit(b))
+        value = complex(self.local.expect_pauli("".join(letters), local)) if local else complex(self.local.norm2())
+        re, im = self._allreduce_sum([sign * value.real, sign * value.imag])
+        return complex(re, im)
+
     def to_numpy(self) -> np.ndarray:
         """The whole ket in reference order, on every rank (tests and small registers only)."""
         import torch

@@ -182,6 +182,18 @@ def main():
     check("controlled gates", st.to_numpy(), want)
     probe = [0, 1, (1 << n) - 1, 37 % (1 << n), 1 << (n - 1)]
     check("probabilities", st.probabilities(probe), np.abs(want[probe]) ** 2, 1e-14)
+    # read-out across the shards: reduced density matrices and Pauli strings with legs on rank bits
+    for kept in ([n - 1], [0], [1, 0, n - 2], [n - 1, 3, 0, 1]):
+        want_now = st.to_numpy()
+        check(f"reduced density {kept}", st.reduced_density(kept), O.reduced_density(want_now, kept), 1e-13)
+    paulis = {"I": np.identity(2), "X": np.array([[0, 1], [1, 0]]), "Y": np.array([[0, -1j], [1j, 0]]), "Z": np.diag([1.0, -1.0])}
+    for letters, qs in (("Z", [0]), ("ZZ", [0, n - 1]), ("XZ", [0, 1]), ("YXZI", [1, n - 1, 0, 2]), ("ZY", [n - 2, 0])):
+        want_now = st.to_numpy()
+        out = want_now
+        for p, q in zip(letters, qs):
+            out = O.apply_gate(out, paulis[p].astype(complex), [q])
+        got = st.expect_pauli(letters, qs)
+        assert abs(got - np.vdot(want_now, out)) < 1e-13, (letters, qs, got)
 
     # 3. measurement (forced outcomes) of a remote and a local qubit, through the Simulator
     ket = W.random_ket(n, 4)

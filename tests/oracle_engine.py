@@ -107,6 +107,17 @@ class OracleEngine:
     def norm2(self) -> float:
         return float(np.sum(np.abs(self.arr) ** 2))
 
+    def reduced_density(self, qubits) -> np.ndarray:
+        return O.reduced_density(self.arr.copy(), list(qubits))
+
+    def expect_pauli(self, paulis: str, qubits) -> complex:
+        letters = {"I": np.identity(2), "X": np.array([[0, 1], [1, 0]]), "Y": np.array([[0, -1j], [1j, 0]]),
+                   "Z": np.diag([1.0, -1.0])}
+        out = self.arr.copy()
+        for p, q in zip(paulis, qubits):
+            out = O.apply_gate(out, letters[p].astype(complex), [q])
+        return complex(np.vdot(self.arr, out))
+
     def probabilities(self, indices) -> np.ndarray:
         return np.abs(self.arr[np.asarray(indices, dtype=np.int64)]) ** 2
 

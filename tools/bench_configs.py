@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Secondary BASELINE.json configurations that fit one MI355X, plus the host<->device transfer rates.
+(Round 2: ``bench.py --config cfg3|cfg4|cfg5`` and the ``secondary`` block of the default bench line cover the same
+configurations in the driver-visible line; this script stays as the longer stand-alone form.)
 
     python tools/bench_configs.py [--out gpurun_out/configs.json] [--grover-n 30] [--skip-cv]
 
@@ -58,7 +60,7 @@ def cv_fock(n_modes: int = 6, d: int = 32, gates: int = 60) -> dict:
         key = (type(g).__name__, g.arg)
         if key not in mats:
             mats[key] = (fock.squeeze_matrix(d, g.arg, 0.0) if isinstance(g, fock.S)
-                         else fock.photon_number_blocks(fock.beamsplitter_matrix(d, g.arg), d))
+                         else fock.beamsplitter_blocks(d, g.arg))
     per_gate = {"S": [], "BS": []}
     st.reg.sync()
     t_all = time.perf_counter()
