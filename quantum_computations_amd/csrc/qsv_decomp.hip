@@ -683,7 +683,7 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
         return !(v && std::string(v) == "exact");
     }();
     double frobenius_squared = -1.0;      // filled in by the verified route when it gets far enough to measure it
-    if (shortcuts_enabled && fused_panels_enabled() && (rel_err >= 1e-4 || abs_err > 0.0)) {
+    if (shortcuts_enabled && fused_panels_enabled()) {     // any tolerance: the route verifies itself (or declines)
         std::vector<double> values;
         const int fast = try_verified_low_rank(a, h, device, stream, theta, rows, cols, max_bond_dim, abs_err, rel_err, m1, m2,
                                                capacity, rank_out, s_host ? &values : nullptr, &frobenius_squared);
@@ -1217,6 +1217,66 @@ __global__ __launch_bounds__(256) void k_small_reorder(const amp_t *__restrict__
     }
 }
 
+// T (n x l, column-major) = Q (n x l, column-major) * R^H with R (l x l) row-major: the projection coefficients
+// Q^H A = R^H Qb^H of the range finder, folded into the left panel.
+__global__ __launch_bounds__(256) void k_panel_times_rh(const amp_t *__restrict__ Q, const amp_t *__restrict__ R,
+                                                        amp_t *__restrict__ T, uint64_t n, int l) {
+    const uint64_t total = n * static_cast<uint64_t>(l);
+    for (uint64_t o = blockIdx.x * 256ull + threadIdx.x; o < total; o += gridDim.x * 256ull) {
+        const uint64_t i = o % n;
+        const int k = static_cast<int>(o / n);
+        double re = 0.0, im = 0.0;
+        for (int p = 0; p < l; ++p) {
+            const amp_t q = Q[i + static_cast<uint64_t>(p) * n], r = R[static_cast<size_t>(k) * l + p];
+            re += q.x * r.x + q.y * r.y;     // q * conj(r)
+            im += q.y * r.x - q.x * r.y;
+        }
+        T[o] = amp_t{re, im};
+    }
+}
+
+// partials[block] = sum over a 16 x 16 tile of |A(i, j) - sum_k T(i, k) conj(Qb(j, k))|^2: the squared Frobenius norm
+// of what the projection misses, entry by entry -- no subtraction of two nearly equal norms, so the result is good
+// down to rounding level (~1e-15 ||A||) instead of ~1e-8 ||A||.  A(i, j) = theta[i * si + j * sj].
+__global__ __launch_bounds__(256) void k_residual_partials(const amp_t *__restrict__ theta, uint64_t si, uint64_t sj,
+                                                           const amp_t *__restrict__ T, const amp_t *__restrict__ Qb,
+                                                           uint64_t n, uint64_t m, int l, double *__restrict__ partials) {
+    __shared__ amp_t ts[16][17], qs[16][17];
+    __shared__ double red[4];
+    const int ti = threadIdx.x & 15, tj = threadIdx.x >> 4;
+    const uint64_t tiles_i = (n + 15) / 16, tiles_j = (m + 15) / 16;
+    double sum = 0.0;
+    for (uint64_t tile = blockIdx.x; tile < tiles_i * tiles_j; tile += gridDim.x) {
+        const uint64_t i0 = (tile % tiles_i) * 16, j0 = (tile / tiles_i) * 16;
+        const uint64_t i = i0 + ti, j = j0 + tj;
+        double re = 0.0, im = 0.0;
+        for (int k0 = 0; k0 < l; k0 += 16) {
+            __syncthreads();
+            // thread (ti, tj) stages T(i0 + ti, k0 + tj) and Qb(j0 + ti, k0 + tj)
+            const int kk = k0 + tj;
+            ts[tj][ti] = (i0 + ti < n && kk < l) ? T[i0 + ti + static_cast<uint64_t>(kk) * n] : amp_t{0.0, 0.0};
+            qs[tj][ti] = (j0 + ti < m && kk < l) ? Qb[j0 + ti + static_cast<uint64_t>(kk) * m] : amp_t{0.0, 0.0};
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const amp_t t = ts[k][ti], q = qs[k][tj];
+                re += t.x * q.x + t.y * q.y;     // t * conj(q)
+                im += t.y * q.x - t.x * q.y;
+            }
+        }
+        if (i < n && j < m) {
+            const amp_t a = theta[i * si + j * sj];
+            const double dr = a.x - re, di = a.y - im;
+            sum += dr * dr + di * di;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 // The randomized split with the fused panel kernels: same algorithm and random stream as below, but every
 // re-orthonormalisation is 9 launches and the l x m projection is decomposed through B^H = Qb Rb and a Jacobi SVD of Rb.
 // `verify` != null switches to the *verified low-rank* mode used by the exact split (see qsvg_svd_split): all l computed
@@ -1239,8 +1299,8 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
     const uint64_t L = static_cast<uint64_t>(l);
     DeviceBuffers buf;
     const uint64_t block = L < LMAX ? L : LMAX, scratch_amps = 2 * LMAX * LMAX;
-    buf.reserve(device, sizeof(amp_t) * ((n + m) * (L + static_cast<uint64_t>(k_keep)) + GRAM_BLOCKS * block * block +
-                                         scratch_amps + 5 * L * L) + 32 * L + 16384);
+    buf.reserve(device, sizeof(amp_t) * ((n + m) * (L + static_cast<uint64_t>(k_keep)) + (verify ? n * L : 0) +
+                                         GRAM_BLOCKS * block * block + scratch_amps + 5 * L * L) + 32 * L + 16384 + 8 * 1024);
     amp_t *Qn = nullptr, *Qm = nullptr, *partials = nullptr, *small = nullptr, *UA = nullptr, *VA = nullptr;
     double *dS = nullptr;
     // small: block scratch (2 x 64 x 64) | r_total | U_r | V_r | library scratch, each L x L
@@ -1316,7 +1376,29 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
         for (double v : sv) captured += v * v;
         const double f2 = verify->frobenius_squared;
         double rho2 = f2 - captured;
-        const double resolution = 4e-16 * static_cast<double>(L) * f2;
+        double resolution = 4e-16 * static_cast<double>(L) * f2;
+        if (rho2 < 1e-6 * f2) {
+            // The difference of the two norms is blind below ~1e-8 ||A||; a tight tolerance (the reference's default
+            // rel_err = 1e-12) needs better.  Evaluate the residual itself: (I - Q Q^H) A = A - (Q Rb^H) Qb^H entry by
+            // entry (A^H Q = Qb Rb was formed above), one l-term dot product per entry, rounding level ~l eps ||A||.
+            amp_t *Tp = nullptr;
+            double *res_partials = nullptr;
+            if (buf.alloc(&Tp, sizeof(amp_t) * n * L) && buf.alloc(&res_partials, sizeof(double) * 1024)) {
+                hipLaunchKernelGGL(k_panel_times_rh, dim3(blocks_for(n * L)), dim3(256), 0, stream, Qn, r_total, Tp, n, l);
+                // A(i, j): wide theta -> A = theta^T: theta[j * cols + i]; tall theta -> A = theta: theta[i * cols + j]
+                hipLaunchKernelGGL(k_residual_partials, dim3(1024), dim3(256), 0, stream, theta, wide ? 1ull : cols,
+                                   wide ? cols : 1ull, Tp, Qm, n, m, l, res_partials);
+                QSV_HIP(hipGetLastError());
+                std::vector<double> parts(1024);
+                QSV_HIP(hipMemcpyAsync(parts.data(), res_partials, sizeof(double) * 1024, hipMemcpyDeviceToHost, stream));
+                QSV_HIP(hipStreamSynchronize(stream));
+                double explicit_rho2 = 0.0;
+                for (double v : parts) explicit_rho2 += v;
+                rho2 = explicit_rho2;
+                // rounding floor of the entry-wise evaluation: each entry carries ~sqrt(l) eps |A_ij| (random signs)
+                resolution = 1e-30 * static_cast<double>(L) * f2;
+            }
+        }
         if (rho2 < resolution) rho2 = resolution;
         const double rho = sqrt(rho2), margin = sqrt(static_cast<double>(verify->full_rank)) * rho;
         const double allowed = allowed_error(sv, abs_err, rel_err);
@@ -1390,51 +1472,22 @@ int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream
                           amp_t *m2, uint64_t capacity, uint64_t *rank_out, std::vector<double> *values,
                           double *frobenius_squared_out) {
     const uint64_t full = rows < cols ? rows : cols;
-    const int l = LMAX, keep = l - 10;          // one 64-column block of probes: everything stays in the fused kernels
-    if (full < 4 * static_cast<uint64_t>(l)) return QSV_UNDECIDED;       // small matrices: the library SVD is cheap
-    // the probe matrix and the norm partials live outside the pool (which rsvd_split_fused carves for itself) and are kept
-    // per device: the probes depend only on the size, so they are generated and uploaded once
+    if (full < 4 * static_cast<uint64_t>(LMAX)) return QSV_UNDECIDED;    // small matrices: the library SVD is cheap
+    // the probe matrices and the norm partials live outside the pool (which rsvd_split_fused carves for itself) and are
+    // kept per device and width: the probes depend only on the size, so they are generated and uploaded once
     struct Probes {
         amp_t *omega = nullptr;
-        double *partials = nullptr;
         uint64_t count = 0;
     };
-    static Probes cache[16];
+    static Probes cache[16][3];
+    static double *norm_partials[16] = {nullptr};
     if (device < 0 || device >= 16) return QSV_UNDECIDED;  // no probe cache for this ordinal: take the exact route
-    Probes &probes = cache[device];
-    if (!probes.partials && hipMalloc(reinterpret_cast<void **>(&probes.partials), sizeof(double) * 256) != hipSuccess) {
-        probes.partials = nullptr;
+    if (!norm_partials[device] &&
+        hipMalloc(reinterpret_cast<void **>(&norm_partials[device]), sizeof(double) * 256) != hipSuccess) {
+        norm_partials[device] = nullptr;
         return QSV_UNDECIDED;
     }
-    if (probes.count != full * l) {
-        if (probes.omega) {
-            (void)hipDeviceSynchronize();
-            (void)hipFree(probes.omega);
-            probes.omega = nullptr;
-            probes.count = 0;
-        }
-        if (hipMalloc(reinterpret_cast<void **>(&probes.omega), sizeof(amp_t) * full * l) != hipSuccess) {
-            probes.omega = nullptr;
-            return QSV_UNDECIDED;
-        }
-        std::vector<double> host(2 * full * l, 0.0);
-        uint64_t state = 0x9e3779b97f4a7c15ull;                          // splitmix64 + Box-Muller: a fixed probe matrix
-        auto next = [&]() {
-            state += 0x9e3779b97f4a7c15ull;
-            uint64_t z = state;
-            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-            z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-            return ((z ^ (z >> 31)) >> 11) * (1.0 / 9007199254740992.0);
-        };
-        for (uint64_t i = 0; i < full * l; ++i) {
-            const double u1 = next() + 1e-300, u2 = next();
-            host[2 * i] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
-        }
-        QSV_HIP(hipMemcpy(probes.omega, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
-        probes.count = full * l;
-    }
-    amp_t *omega = probes.omega;
-    double *partials = probes.partials;
+    double *partials = norm_partials[device];
     hipLaunchKernelGGL(k_sum_squares, dim3(256), dim3(256), 0, stream, theta, rows * cols, partials);
     QSV_HIP(hipGetLastError());
     double sums[256];
@@ -1444,14 +1497,49 @@ int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream
     for (double v : sums) check.frobenius_squared += v;
     if (frobenius_squared_out) *frobenius_squared_out = check.frobenius_squared;
     if (!(check.frobenius_squared > 0.0)) return QSV_UNDECIDED;
-    {   // a tolerance below ~1e-5 ||theta||_F can never clear the resolution of the residual: do not even try
-        const double norm = sqrt(check.frobenius_squared), allowed_at_least = abs_err > rel_err * norm ? abs_err : rel_err * norm;
-        if (allowed_at_least < 1e-5 * norm) return QSV_UNDECIDED;
+    // One 64-column block of probes keeps everything in the fused kernels; when the numerical rank does not fit (the kept
+    // triplets must leave ten probes of oversampling and stand well above what was missed) the panel is widened to 128 and
+    // 256 probes (64-column blocks, Jacobi sweeps in global memory) before the library SVD gets the matrix: even the
+    // widest attempt costs tens of milliseconds where zgesvd takes seconds on these graded spectra.
+    const int widths[3] = {LMAX, 2 * LMAX, WIDE_MAX};
+    for (int w = 0; w < 3; ++w) {
+        const int l = widths[w], keep = l - 10;
+        if (full < 4 * static_cast<uint64_t>(l)) break;
+        Probes &probes = cache[device][w];
+        if (probes.count != full * l) {
+            if (probes.omega) {
+                (void)hipDeviceSynchronize();
+                (void)hipFree(probes.omega);
+                probes.omega = nullptr;
+                probes.count = 0;
+            }
+            if (hipMalloc(reinterpret_cast<void **>(&probes.omega), sizeof(amp_t) * full * l) != hipSuccess) {
+                probes.omega = nullptr;
+                return QSV_UNDECIDED;
+            }
+            std::vector<double> host(2 * full * l, 0.0);
+            uint64_t state = 0x9e3779b97f4a7c15ull + static_cast<uint64_t>(w);   // splitmix64 + Box-Muller: fixed probe matrices
+            auto next = [&]() {
+                state += 0x9e3779b97f4a7c15ull;
+                uint64_t z = state;
+                z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+                z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+                return ((z ^ (z >> 31)) >> 11) * (1.0 / 9007199254740992.0);
+            };
+            for (uint64_t i = 0; i < full * l; ++i) {
+                const double u1 = next() + 1e-300, u2 = next();
+                host[2 * i] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+            }
+            QSV_HIP(hipMemcpy(probes.omega, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
+            probes.count = full * l;
+        }
+        // two power iterations: the route is accepted only when the kept values stand 10^2 rho above everything that was
+        // missed, and the error of their subspace after q iterations is of order (missed / kept)^(2q+1)
+        const int rc = rsvd_split_fused(a, h, device, stream, theta, rows, cols, keep, l, 2, probes.omega, abs_err, rel_err, m1,
+                                        m2, capacity, rank_out, nullptr, &check);
+        if (rc != QSV_UNDECIDED) return rc;
     }
-    // two power iterations: the route is accepted only when the kept values stand 10^3 rho above everything that was
-    // missed, and the error of their subspace after q iterations is of order (missed / kept)^(2q+1)
-    return rsvd_split_fused(a, h, device, stream, theta, rows, cols, keep, l, 2, omega, abs_err, rel_err, m1, m2, capacity,
-                            rank_out, nullptr, &check);
+    return QSV_UNDECIDED;
 }
 
 // tensor_svd on its randomized branch (mps.py:5-50,78-79; Halko, Martinsson & Tropp 2010): range finder with

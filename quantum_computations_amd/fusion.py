@@ -109,11 +109,31 @@ def fuse_circuit(circuit: list, max_qubits: int = 4, n_qubits: int | None = None
             out.append(b.emit())
             open_blocks.remove(b)
 
+    def effective_size(block) -> int:
+        qs = set(block.qubits)
+        return len(qs) - len({q for q in qs & remote if all(_conserves(g, q) for g in block.gates)})
+
+    def flush_all():
+        """Everything goes out (a barrier or the end of the circuit): open blocks act on disjoint qubits, so they commute
+        and may share launches -- pack them, largest first, into tensor products of at most ``max_qubits`` qubits."""
+        blocks = sorted(open_blocks, key=effective_size, reverse=True)
+        packed: list[_Block] = []
+        for b in blocks:
+            for host in packed:
+                if effective_size(host) + effective_size(b) <= max_qubits and len(host.qubits) + len(b.qubits) <= MAX_LEGS:
+                    host.merge(b)
+                    break
+            else:
+                packed.append(b)
+        for b in packed:
+            out.append(b.emit())
+        open_blocks.clear()
+
     for gate in circuit:
         plain = isinstance(gate, Gate) and not isinstance(gate, (M, Insert)) and gate.matrix is not None \
             and gate.matrix.shape[0] == gate.matrix.shape[1]
         if not plain or len(gate.indices) > min(max_qubits, MAX_LEGS):
-            flush(list(open_blocks))
+            flush_all()
             out.append(gate)
             continue
         touched = [b for b in open_blocks if set(b.qubits) & set(gate.indices)]
@@ -126,9 +146,23 @@ def fuse_circuit(circuit: list, max_qubits: int = 4, n_qubits: int | None = None
             first.grow(list(gate.indices))
             first.absorb(gate)
         else:
-            flush(touched)
-            open_blocks.append(_Block(gate))
-    flush(list(open_blocks))
+            # too many qubits together: let the largest touched blocks go until the rest and the gate fit one block
+            touched.sort(key=lambda b: len(b.qubits), reverse=True)
+            while touched:
+                flush([touched.pop(0)])
+                union = set(gate.indices).union(*(b.qubits for b in touched))
+                if touched and allowed(union, [g for b in touched for g in b.gates], gate):
+                    break
+            if touched:
+                first = touched[0]
+                for other in touched[1:]:
+                    first.merge(other)
+                    open_blocks.remove(other)
+                first.grow(list(gate.indices))
+                first.absorb(gate)
+            else:
+                open_blocks.append(_Block(gate))
+    flush_all()
     return out
 
 

@@ -191,3 +191,33 @@ def test_randomized_split_with_wide_panels(rows, cols, cap):
     m1, m2 = tensor_svd(a.reshape(rows, 1, 1, cols), [0, 1], [2, 3], max_bond_dim=cap, rng_seed=17)
     assert m1.shape[-1] == want1.shape[1]
     assert maxdiff(np.tensordot(m1, m2, axes=1).reshape(rows, cols), want1 @ want2) < 1e-9
+
+
+@pytest.mark.parametrize("rows,cols,rank,decay", [(1400, 1100, 12, 0.7), (1000, 2000, 45, 0.25), (1800, 1800, 100, 0.12),
+                                                 (1300, 1500, 230, 0.05), (1200, 1200, 700, 0.02)])
+def test_exact_split_at_the_default_tolerance(rows, cols, rank, decay):
+    """The reference's default ``rel_err = 1e-12`` on numerically low-rank theta of the sizes its GKP runs produce
+    (1000..2000 on a side): the verified route evaluates what its projection misses entry by entry (resolution
+    ~1e-15 ||theta||, not the ~1e-8 of a difference of norms) and widens its probe panel 64 -> 128 -> 256 before the
+    library SVD gets the matrix.  Whatever route answers, the kept rank must be the one the truncation rule gives on
+    LAPACK's spectrum and the product must match the exactly truncated one -- including spectra that do NOT fit 256
+    probes (the last case: the library decides)."""
+    import time
+    from oracle import mps_oracle as MO
+    rng = np.random.default_rng(rows + rank)
+    full = min(rows, cols)
+    u, _ = np.linalg.qr(rng.standard_normal((rows, full)) + 1j * rng.standard_normal((rows, full)))
+    v, _ = np.linalg.qr(rng.standard_normal((cols, full)) + 1j * rng.standard_normal((cols, full)))
+    spectrum = np.exp(-decay * np.arange(full))
+    spectrum[rank:] = 1e-16 * rng.random(full - rank)                       # exactly low rank up to rounding dust
+    a = (u * spectrum) @ v.conj().T
+    want1, want2 = MO.split(a)                                               # rel_err = 1e-12, no cap, no abs_err
+    tensor_svd(a.reshape(rows, 1, 1, cols), [0, 1], [2, 3])                  # warm-up: library loads, probe upload
+    t0 = time.perf_counter()
+    m1, m2 = tensor_svd(a.reshape(rows, 1, 1, cols), [0, 1], [2, 3])
+    seconds = time.perf_counter() - t0
+    assert m1.shape[-1] == want1.shape[1], (m1.shape[-1], want1.shape[1])
+    got = np.tensordot(m1, m2, axes=1).reshape(rows, cols)
+    assert maxdiff(got, want1 @ want2) < 1e-11
+    if rank <= 230:
+        assert seconds < 1.0, seconds                # not the seconds-long zgesvd
