@@ -7,6 +7,7 @@ The kernels use fp64 FMA, NumPy does not, and the summation orders differ -- hen
 from __future__ import annotations
 
 import numpy as np
+from pathlib import Path
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -654,6 +655,24 @@ def test_sharded_state_on_one_gpu(world):
     # (slicing of the shard, two-slice staging buffer, copies into place); only the send/recv itself is host-staged
     out = run_workers(world, "--backend", "gloo-gpu", "--qubits", "12", "--chunk-amps", "64")
     assert f"dist_worker ok: world={world} backend=gloo-gpu" in out and "chunk_amps=64" in out
+
+
+@pytest.mark.parametrize("n", [30, 32])
+def test_large_sharded_register_at_the_production_piece_size(n):
+    """Two ranks on the one GPU with 8 GiB and 32 GiB shards (32 GiB is the shard of BASELINE config 3: 34 qubits on 8
+    GPUs): the half shard travels in 4 / 16 pieces of 1 GiB through the two-piece staging buffer (device tensors beyond
+    2^31 bytes, the default chunk size).  Known answers and circuit + inverse; no CPU oracle can hold these registers."""
+    import os
+    import subprocess
+    import sys
+    from test_distributed_gloo import free_port
+    env = dict(os.environ, OMP_NUM_THREADS="4", MASTER_ADDR="127.0.0.1")
+    env.pop("QSV_EXCHANGE_CHUNK_AMPS", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(Path(__file__).resolve().parent / "dist_big_worker.py"), "--qubits", str(n)]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-3000:] + "\n" + proc.stderr[-3000:]
+    assert f"dist_big_worker ok: n={n}" in proc.stdout
 
 
 # ---- d-level modes --------------------------------------------------------------------------------------------
