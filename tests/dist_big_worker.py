@@ -1,4 +1,4 @@
-"""Worker of the large sharded-register test: 2 ranks on ONE GPU (send/recv staged through the host over gloo), a
+"""Worker of the large sharded-register test: 2 (or 4) ranks on ONE GPU (send/recv staged through the host over gloo), a
 register of ``--qubits`` qubits (default 30: two 8 GiB shards), exchanges at the production piece size of 1 GiB, so the
 half shard of 4 GiB travels in four double-buffered slices on device tensors.  No CPU oracle can hold this register:
 the checks are known answers (basis states pushed around by X / CX / SWAP through rank bits), a circuit followed by its
@@ -45,7 +45,13 @@ def main():
     st.set_basis(0)
     top = 1 << (n - 1)
     G.X(0).apply(st)                                      # mixes the remote qubit: one exchange
-    assert st.exchanges == 1 and st.messages == max(1, (1 << (n_local - 1)) >> 26)
+    assert st.exchanges == 1
+    if world == 2:
+        assert st.messages == max(1, (1 << (n_local - 1)) >> 26)          # the half shard in 1 GiB slices
+    else:
+        piece = (1 << n_local) // world                                    # all rank bits at once: shard / G to every peer
+        slice_amps = 1 << (((1 << 26) // (world - 1)).bit_length() - 1)
+        assert st.messages == (world - 1) * max(1, piece // slice_amps) and st.qubits_exchanged == (world - 1).bit_length()
     assert abs(st.probabilities([top])[0] - 1.0) < 1e-14
     G.CX(0, n - 1).apply(st)
     assert abs(st.probabilities([top | 1])[0] - 1.0) < 1e-14

@@ -657,18 +657,19 @@ def test_sharded_state_on_one_gpu(world):
     assert f"dist_worker ok: world={world} backend=gloo-gpu" in out and "chunk_amps=64" in out
 
 
-@pytest.mark.parametrize("n", [30, 32])
-def test_large_sharded_register_at_the_production_piece_size(n):
+@pytest.mark.parametrize("n,world", [(30, 2), (32, 2), (31, 4)])
+def test_large_sharded_register_at_the_production_piece_size(n, world):
     """Two ranks on the one GPU with 8 GiB and 32 GiB shards (32 GiB is the shard of BASELINE config 3: 34 qubits on 8
     GPUs): the half shard travels in 4 / 16 pieces of 1 GiB through the two-piece staging buffer (device tensors beyond
-    2^31 bytes, the default chunk size).  Known answers and circuit + inverse; no CPU oracle can hold these registers."""
+    2^31 bytes, the default chunk size); with four ranks all rank bits are exchanged at once (three peers, 256 MiB
+    slices).  Known answers and circuit + inverse; no CPU oracle can hold these registers."""
     import os
     import subprocess
     import sys
     from test_distributed_gloo import free_port
     env = dict(os.environ, OMP_NUM_THREADS="4", MASTER_ADDR="127.0.0.1")
     env.pop("QSV_EXCHANGE_CHUNK_AMPS", None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), str(Path(__file__).resolve().parent / "dist_big_worker.py"), "--qubits", str(n)]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stdout[-3000:] + "\n" + proc.stderr[-3000:]
