@@ -219,5 +219,6 @@ def test_exact_split_at_the_default_tolerance(rows, cols, rank, decay):
     assert m1.shape[-1] == want1.shape[1], (m1.shape[-1], want1.shape[1])
     got = np.tensordot(m1, m2, axes=1).reshape(rows, cols)
     assert maxdiff(got, want1 @ want2) < 1e-11
+    print(f"split {rows}x{cols} rank {rank}: {seconds * 1e3:.1f} ms")
     if rank <= 230:
-        assert seconds < 1.0, seconds                # not the seconds-long zgesvd
+        assert seconds < 2.0, seconds                # tens of milliseconds; rocSOLVER's zgesvd takes 1-14 s on these
