@@ -380,6 +380,7 @@ class ShardedState:
         self._plan, self._cursor, self._done = plan, 0, [False] * len(plan)
 
     PLAN_WINDOW = 512      # how far ahead of the first pending entry an announced gate may arrive
+    PLAN_HORIZON = 4096    # how far ahead the eviction rule looks for a qubit's next use (beyond: "far")
 
     def _advance_plan(self, indices) -> None:
         if self._plan is None:
@@ -395,7 +396,7 @@ class ShardedState:
 
     def _next_mixing_use(self, qubit: int) -> int:
         """First pending plan step that mixes the data now known as ``qubit`` (SWAPs ahead rename it on the way)."""
-        for step in range(self._cursor, len(self._plan)):
+        for step in range(self._cursor, min(len(self._plan), self._cursor + self.PLAN_HORIZON)):
             if self._done[step]:
                 continue
             indices, mixing, relabel = self._plan[step]
@@ -425,12 +426,15 @@ class ShardedState:
         layer.  A layer of one-qubit gates on all n qubits (Grover's H and X walls) then costs one exchange instead
         of one per remote qubit per wall.  Returns the gates in the order applied; ``apply(gate)`` does the
         application (default ``gate.apply(self)``) and may return False to say the gate was skipped."""
-        pending = list(circuit)
+        from collections import deque
+        from itertools import islice
+
+        pending = deque(circuit)
         self.prepare(pending)
         order = []
         while pending:
             pick, used = 0, set()
-            for j, gate in enumerate(pending[:256]):
+            for j, gate in enumerate(islice(pending, 256)):
                 inner = getattr(gate, "gate", gate)
                 if inner is not gate or self.mixing_qubits(gate) is None:
                     break                                            # barriers are taken only from the front
@@ -441,7 +445,9 @@ class ShardedState:
                 if not self.needs_exchange(gate):
                     pick = j
                     break
-            gate = pending.pop(pick)
+            pending.rotate(-pick)                                    # O(pick), whatever the length of the circuit
+            gate = pending.popleft()
+            pending.rotate(pick)
             order.append(gate)
             if apply is not None:
                 apply(gate)
