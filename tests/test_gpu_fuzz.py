@@ -19,3 +19,11 @@ def test_random_operation_sequences_match_the_oracle(seed):
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
     assert "fuzz ok: 80 rounds" in proc.stdout
     assert "k_dense_lds<5" in proc.stdout and "k_rdm<" in proc.stdout and "k_permute_s" in proc.stdout
+
+
+@pytest.mark.gpu
+def test_random_mode_operation_sequences_match_the_oracle():
+    proc = subprocess.run([sys.executable, str(REPO / "tools" / "fuzz_modes.py"), "--rounds", "80", "--seed", "21"],
+                          capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    assert "fuzz ok: 80 rounds" in proc.stdout and "k_mode2_blocks<" in proc.stdout
