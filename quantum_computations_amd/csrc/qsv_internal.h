@@ -34,7 +34,7 @@ struct GateArgs {
     int32_t ubit;        // the U work items of a thread are 2^ubit items apart (8 = consecutive 256-item tiles)
     int32_t lbit[2];     // positions of the low target bits (bit j of l)
     int32_t lxor[4];     // lane xor mask of low-bit combination x
-    uint8_t pos[QSV_MAX_INS];
+    uint32_t pos[QSV_MAX_INS];   // 32-bit on purpose: a dword array in the kernarg segment is indexed with scalar loads
     double m[32];        // matrix in kernel order: row = (h << KL) | l, interleaved complex, row-major
 };
 
@@ -47,7 +47,7 @@ struct DiagArgs {
     uint32_t lane_ctrl;
     int32_t b0, b1;
     int32_t remap;
-    uint8_t pos[QSV_MAX_INS];
+    uint32_t pos[QSV_MAX_INS];   // 32-bit on purpose: a dword array in the kernarg segment is indexed with scalar loads
     double d[8];
 };
 

@@ -68,9 +68,14 @@ __device__ __forceinline__ uint64_t insert_zero(uint64_t w, int p) {
     return ((w >> p) << (p + 1)) | low;
 }
 
-template <class Args>
+// The positions are 32-bit words on purpose.  The argument struct lives in the kernarg segment; a run-time index into
+// a BYTE array there makes the compiler fetch the byte with a vector load (gfx950 has no sub-dword scalar loads)
+// followed by s_waitcnt vmcnt(0) in front of every amplitude load -- which also drains every amplitude load already in
+// flight (k_rdm ran at 1.3-2.3 TB/s that way; rocprof: 60-70 % of the wave cycles parked).  A dword array is indexed
+// with s_load_dword.
+template <int STATIC = 4, class Args>
 __device__ __forceinline__ uint64_t deposit(uint64_t w, const Args &g) {
-    for (int j = 0; j < g.nins; ++j) w = insert_zero(w, g.pos[j]);
+    for (int j = 0; j < g.nins; ++j) w = insert_zero(w, static_cast<int>(g.pos[j]));
     return w | g.or_mask;
 }
 
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_generic(amp_t *__restrict__ a, co
 struct BigArgs {
     uint64_t W;
     int32_t nins;
-    uint8_t pos[2 * QSV_MAX_K];  // ascending: high targets and stand-in bits
+    uint32_t pos[2 * QSV_MAX_K];  // ascending: high targets and stand-in bits
     uint64_t or_mask;            // unused (0); lets deposit() serve this struct too
     uint64_t w0;                 // first work item of this launch (registers beyond 2^32 work items take several)
     uint32_t regions;            // tile order (see GateArgs::remap)
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_dense_big(amp_t *__restrict__ a, 
                               : blockIdx.x;
     const uint64_t w = g.w0 + tile * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x;
     if (w >= g.W) return;  // W and w0 are multiples of 64 whenever KL > 0: whole waves leave together
-    const uint64_t base = deposit(w, g);
+    const uint64_t base = deposit<10>(w, g);
     amp_t x[D];
 #pragma unroll
     for (int c = 0; c < D; ++c) x[c] = ld<NT>(a + base + hoff[c]);
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_dense_big(amp_t *__restrict__ a, 
 struct LdsArgs {
     uint64_t W;
     int32_t nins;
-    uint8_t pos[2 * QSV_MAX_K];  // ascending: high targets and stand-in bits
+    uint32_t pos[2 * QSV_MAX_K];  // ascending: high targets and stand-in bits
     uint64_t or_mask;            // unused (0); lets deposit() serve this struct too
     uint64_t w0;                 // first work item of this launch
     uint32_t regions;            // tile order (see GateArgs::remap)
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(BLOCK) void k_dense_lds(amp_t *__restrict__ a, cons
     if (w >= g.W) return;  // W and w0 are multiples of 64: whole waves leave together
     const uint32_t lane = threadIdx.x & 63;
     // row of this lane: its A bits move from the column to the stand-in bits
-    uint64_t base = deposit(w, g) & ~static_cast<uint64_t>(g.amask);
+    uint64_t base = deposit<10>(w, g) & ~static_cast<uint64_t>(g.amask);
     for (int j = 0; j < g.na; ++j) base |= static_cast<uint64_t>((lane >> g.abit[j]) & 1u) << g.aE[j];
     amp_t x[D];
 #pragma unroll
@@ -483,7 +488,7 @@ struct Mfma6Args {
     uint64_t W;          // groups = amps / 64
     uint64_t or_mask;    // unused (0); lets deposit() serve this struct too
     int32_t nins;        // 6
-    uint8_t pos[8];      // ascending target bits (all >= 4)
+    uint32_t pos[8];     // ascending target bits (all >= 4)
 };
 
 template <bool NT, bool REALM>
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_dense6_mfma(amp_t *__restrict__ a
     const uint64_t wave = blockIdx.x * (QSV_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t waves = static_cast<uint64_t>(gridDim.x) * (QSV_BLOCK / 64);
     for (uint64_t tile = wave; tile * 16 < g.W; tile += waves) {
-        const uint64_t base = deposit(tile * 16 + li, g);
+        const uint64_t base = deposit<6>(tile * 16 + li, g);
         amp_t x[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) x[s] = ld<NT>(a + base + off[4 * s + lk]);
@@ -1030,8 +1035,15 @@ struct RdmArgs {
     uint64_t or_mask;    // unused (0); lets deposit() serve this struct too
     int32_t nins;        // k
     int32_t D;           // 2^k
-    uint8_t pos[8];      // ascending kept bits
+    uint32_t pos[8];     // ascending kept bits
 };
+
+// RDM_U quads of groups are loaded before the first MFMA of an iteration (a wave with a single 16-byte load in flight
+// spends its life waiting for HBM: 0.25-1.3 TB/s in the first version of this kernel).  When 2^k < 16 the sixteen rows
+// of the tile are shared by S = 16 / 2^k groups (row i = r + 2^k s): every lane still loads a different amplitude, the
+// tile then holds S x S blocks of which only the S diagonal ones (same group on both sides) mean anything; the host adds
+// those up.
+constexpr int RDM_U = 4;
 
 template <int T>
 __global__ __launch_bounds__(QSV_BLOCK) void k_rdm(const amp_t *__restrict__ a, const RdmArgs g,
@@ -1040,38 +1052,72 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_rdm(const amp_t *__restrict__ a, 
     constexpr int P = T * (T + 1) / 2;
     __shared__ double red[P * 2 * 256];
     const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+    const int S = T == 1 ? 16 / g.D : 1;                 // groups sharing the 16 rows of a tile (D = 1 never occurs)
+    const uint64_t sub = T == 1 ? static_cast<uint64_t>(i / g.D) : 0;
     uint64_t row_off[T];
-    bool row_ok[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        row_ok[t] = 16 * t + i < g.D;
-        row_off[t] = row_ok[t] ? hoff[16 * t + i] : 0;
-    }
-    f64x4 re[P], im[P];
+    for (int t = 0; t < T; ++t) row_off[t] = hoff[T == 1 ? i % g.D : 16 * t + i];
+    // C independent accumulator sets: consecutive MFMAs never wait for one another's result (with one set per tile
+    // pair the two updates of `re` and of `im` in a step are back-to-back dependent issues of a 64-cycle instruction)
+    constexpr int C = T == 1 ? RDM_U : T == 2 ? 2 : 1;
+    f64x4 re[C][P], im[C][P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) re[p] = im[p] = f64x4{0.0, 0.0, 0.0, 0.0};
-    const uint64_t quads = g.W >> 2;
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int p = 0; p < P; ++p) re[c][p] = im[c][p] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const uint64_t steps = g.W / (4 * static_cast<uint64_t>(S));   // a step = 4 S groups = one MFMA k-slice per tile pair
     const uint64_t wave = blockIdx.x * (QSV_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t waves = static_cast<uint64_t>(gridDim.x) * (QSV_BLOCK / 64);
-    for (uint64_t q = wave; q < quads; q += waves) {
-        const uint64_t base = deposit(4 * q + kk, g);
-        amp_t x[T];
+    auto fetch = [&](amp_t (&x)[RDM_U][T], uint64_t q0) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            x[t] = amp_t{0.0, 0.0};
-            if (row_ok[t]) x[t] = __builtin_nontemporal_load(a + base + row_off[t]);
-        }
-        int p = 0;
+        for (int u = 0; u < RDM_U; ++u) {
+            const uint64_t base = deposit<6>(((q0 + u) * 4 + kk) * S + sub, g);
 #pragma unroll
-        for (int ti = 0; ti < T; ++ti)
-#pragma unroll
-            for (int tj = ti; tj < T; ++tj, ++p) {
-                re[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti].x, x[tj].x, re[p], 0, 0, 0);
-                im[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti].y, x[tj].x, im[p], 0, 0, 0);
-                re[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti].y, x[tj].y, re[p], 0, 0, 0);
-                im[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[ti].x, x[tj].y, im[p], 0, 0, 0);
+            for (int t = 0; t < T; ++t) {
+                x[u][t] = amp_t{0.0, 0.0};
+                if (q0 + u < steps) x[u][t] = __builtin_nontemporal_load(a + base + row_off[t]);
             }
+        }
+    };
+    amp_t x[RDM_U][T], nxt[RDM_U][T];
+    fetch(x, wave * RDM_U);
+    for (uint64_t q0 = wave * RDM_U; q0 < steps; q0 += waves * RDM_U) {
+        fetch(nxt, q0 + waves * RDM_U);        // the next iteration's loads fly while this one's MFMAs run
+        // first halves of every sum, then second halves: 2 C P independent instructions between dependent ones
+#pragma unroll
+        for (int u = 0; u < RDM_U; ++u) {
+            int p = 0;
+#pragma unroll
+            for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < T; ++tj, ++p) {
+                    re[u % C][p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][ti].x, x[u][tj].x, re[u % C][p], 0, 0, 0);
+                    im[u % C][p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][ti].y, x[u][tj].x, im[u % C][p], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < RDM_U; ++u) {
+            int p = 0;
+#pragma unroll
+            for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < T; ++tj, ++p) {
+                    re[u % C][p] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][ti].y, x[u][tj].y, re[u % C][p], 0, 0, 0);
+                    im[u % C][p] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[u][ti].x, x[u][tj].y, im[u % C][p], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < RDM_U; ++u)
+#pragma unroll
+            for (int t = 0; t < T; ++t) x[u][t] = nxt[u][t];
     }
+#pragma unroll
+    for (int c = 1; c < C; ++c)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            re[0][p] += re[c][p];
+            im[0][p] += im[c][p];
+        }
     // deterministic sum over the four waves of the workgroup, then one partial per workgroup
     for (int wv = 0; wv < QSV_BLOCK / 64; ++wv) {
         if ((threadIdx.x >> 6) == wv) {
@@ -1081,8 +1127,8 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_rdm(const amp_t *__restrict__ a, 
                 for (int r = 0; r < 4; ++r) {
                     double *slot_re = red + ((p * 2 + 0) * 4 + r) * 64 + lane;
                     double *slot_im = red + ((p * 2 + 1) * 4 + r) * 64 + lane;
-                    *slot_re = (wv == 0 ? 0.0 : *slot_re) + re[p][r];
-                    *slot_im = (wv == 0 ? 0.0 : *slot_im) + im[p][r];
+                    *slot_re = (wv == 0 ? 0.0 : *slot_re) + re[0][p][r];
+                    *slot_im = (wv == 0 ? 0.0 : *slot_im) + im[0][p][r];
                 }
         }
         __syncthreads();
@@ -1091,14 +1137,25 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_rdm(const amp_t *__restrict__ a, 
     for (int e = threadIdx.x; e < P * 2 * 256; e += QSV_BLOCK) out[e] = red[e];
 }
 
-// out[e] = sum over blocks (in index order) of partials[block][e]
+// out[e] = sum over blocks of partials[block][e].  16 entries x 16 slices per workgroup: slice s adds blocks s, s+16, ...
+// in order, the 16 slice sums are added in slice order through LDS -- a fixed summation tree, so the result does not
+// depend on scheduling (one thread per entry walking every block took 0.24 ms: a chain of ~1000 dependent-latency loads).
 __global__ __launch_bounds__(QSV_BLOCK) void k_sum_partials(const double *__restrict__ partials, int blocks, int entries,
                                                             double *__restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= entries) return;
+    __shared__ double part[16][17];
+    const int le = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + le;
     double s = 0.0;
-    for (int b = 0; b < blocks; ++b) s += partials[static_cast<size_t>(b) * entries + e];
-    out[e] = s;
+    if (e < entries)
+        for (int b = slice; b < blocks; b += 16) s += partials[static_cast<size_t>(b) * entries + e];
+    part[slice][le] = s;
+    __syncthreads();
+    if (slice == 0 && e < entries) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][le];
+        out[e] = t;
+    }
 }
 
 // Small registers: one thread per entry (i, j) of rho walks every group (2^n amplitudes < 2^14: microseconds).
@@ -1301,7 +1358,7 @@ int fill_enumeration(const qsv_state *st, Args &g, const std::vector<int> &remov
     std::sort(ins.begin(), ins.end());
     if (ins.size() > static_cast<size_t>(QSV_MAX_INS)) return qsv_fail(QSV_EINVAL, "too many controls");
     g.nins = static_cast<int>(ins.size());
-    for (size_t i = 0; i < ins.size(); ++i) g.pos[i] = static_cast<uint8_t>(ins[i]);
+    for (size_t i = 0; i < ins.size(); ++i) g.pos[i] = static_cast<uint32_t>(ins[i]);
     g.W = st->amps >> ins.size();
     return QSV_OK;
 }
@@ -1503,7 +1560,7 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
         std::memset(&g, 0, sizeof(g));
         g.W = W;
         g.nins = static_cast<int>(ins.size());
-        for (size_t j = 0; j < ins.size(); ++j) g.pos[j] = static_cast<uint8_t>(ins[j]);
+        for (size_t j = 0; j < ins.size(); ++j) g.pos[j] = static_cast<uint32_t>(ins[j]);
         for (int j = 0; j < KL; ++j) {
             if (low[j] >= 3) {
                 g.abit[g.na] = low[j];
@@ -1537,7 +1594,7 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     for (int j = 0; j < KL; ++j) g.lbit[j] = low[j];
     g.W = W;
     g.nins = static_cast<int>(ins.size());
-    for (size_t j = 0; j < ins.size(); ++j) g.pos[j] = static_cast<uint8_t>(ins[j]);
+    for (size_t j = 0; j < ins.size(); ++j) g.pos[j] = static_cast<uint32_t>(ins[j]);
     // partial-line nontemporal accesses are slow: use them only when every access is a full 1 KiB per wave
     bool coalesced = true;
     for (int b : ins) coalesced = coalesced && b >= QSV_LANE_BITS;
@@ -1612,7 +1669,7 @@ static int launch_dense6(qsv_state *st, const int *bits, const double *m_user) {
     std::memset(&g, 0, sizeof(g));
     g.W = st->amps >> 6;
     g.nins = 6;
-    for (int i = 0; i < 6; ++i) g.pos[i] = static_cast<uint8_t>(sorted[i]);
+    for (int i = 0; i < 6; ++i) g.pos[i] = static_cast<uint32_t>(sorted[i]);
     const bool nt = st->nontemporal != 0;
     const size_t lds = sizeof(double) * (real_matrix ? 4096 : 8192) + sizeof(uint64_t) * 64;
     int cus = 256;
@@ -1977,11 +2034,13 @@ int qsvk_reduced_density(qsv_state *st, int k, const int *bits, double *rho_out)
     g.W = st->amps >> k;
     g.nins = k;
     g.D = D;
-    for (int i = 0; i < k; ++i) g.pos[i] = static_cast<uint8_t>(sorted[i]);
-    const bool big = st->n >= RO_MIN_QUBITS && g.W % 4 == 0;
+    for (int i = 0; i < k; ++i) g.pos[i] = static_cast<uint32_t>(sorted[i]);
+    const int S = D < 16 ? 16 / D : 1;                   // groups sharing a 16-row tile (k_rdm)
+    const bool big = st->n >= RO_MIN_QUBITS && g.W % (4 * static_cast<uint64_t>(S)) == 0;
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st->device);  // 256 if the query fails
-    const int blocks = big ? static_cast<int>(std::min<uint64_t>(2ull * cus, std::max<uint64_t>(1, (g.W >> 2) / 4))) : 0;
+    const int blocks =
+        big ? static_cast<int>(std::min<uint64_t>((T <= 2 ? 4ull : 2ull) * cus, std::max<uint64_t>(1, g.W / (4ull * S) / (4 * RDM_U)))) : 0;
     const int entries = big ? P * 2 * 256 : 2 * D * D;
     const size_t b_off = sizeof(uint64_t) * off.size(), b_out = sizeof(double) * entries,
                  b_part = sizeof(double) * static_cast<size_t>(blocks) * entries;
@@ -1999,7 +2058,7 @@ int qsvk_reduced_density(qsv_state *st, int k, const int *bits, double *rho_out)
         else hipLaunchKernelGGL(k_rdm<4>, dim3(blocks), dim3(QSV_BLOCK), 0, st->stream, st->data, g, d_off, d_part);
         rc = check_launch();
         if (rc) return rc;
-        hipLaunchKernelGGL(k_sum_partials, dim3((entries + QSV_BLOCK - 1) / QSV_BLOCK), dim3(QSV_BLOCK), 0, st->stream, d_part,
+        hipLaunchKernelGGL(k_sum_partials, dim3((entries + 15) / 16), dim3(QSV_BLOCK), 0, st->stream, d_part,
                            blocks, entries, d_out);
     } else {
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_rdm_small");
@@ -2031,9 +2090,13 @@ int qsvk_reduced_density(qsv_state *st, int k, const int *bits, double *rho_out)
                 int pidx = 0;
                 for (int a = 0; a < ti; ++a) pidx += T - a;
                 pidx += tj - ti;
-                const int row = rr % 16, col = cc % 16, reg = row / 4, lane = (row % 4) * 16 + col;
-                vr = raw[((pidx * 2 + 0) * 4 + reg) * 64 + lane];
-                vi = raw[((pidx * 2 + 1) * 4 + reg) * 64 + lane];
+                vr = vi = 0.0;
+                for (int sgrp = 0; sgrp < S; ++sgrp) {   // 2^k < 16: the diagonal blocks of the shared tile add up
+                    const int row = rr % 16 + D * sgrp * (D < 16), col = cc % 16 + D * sgrp * (D < 16);
+                    const int reg = row / 4, lane = (row % 4) * 16 + col;
+                    vr += raw[((pidx * 2 + 0) * 4 + reg) * 64 + lane];
+                    vi += raw[((pidx * 2 + 1) * 4 + reg) * 64 + lane];
+                }
                 if (!upper) vi = -vi;  // rho[r][c] = conj(rho[c][r])
                 if (r == c) vi = 0.0;
             } else {

@@ -74,6 +74,14 @@ def main():
     ms = timed(lambda: dev.expect_pauli("XZY", [0, n // 2, n - 1]))
     report("expect_pauli", "X(0) Z(n/2) Y(n-1)", ms, 2 * amp_gb, "reads psi[i] and psi[i ^ xmask]")
 
+    emit("\n## reduced density matrices (read every amplitude once; X X^H on the f64 matrix cores)")
+    for label, bits in {"k=1 low": [0], "k=1 high": [n - 1], "k=2 mixed": [1, 20], "k=3 low": [0, 1, 2], "k=3 high": [n - 3, n - 2, n - 1],
+                        "k=4 mixed": [0, 5, 12, 25], "k=5 low": [0, 1, 2, 3, 4], "k=5 high": [10, 14, 18, 22, 26],
+                        "k=6 low": [0, 1, 2, 3, 4, 5], "k=6 mixed": [2, 6, 11, 17, 23, n - 1]}.items():
+        qs = [n - 1 - b for b in bits]
+        ms = timed(lambda: dev.reduced_density(qs), reps=3)
+        report("reduced_density", label, ms, amp_gb, f"{dev.last_kernel()} (includes the partial sums and the download of rho)")
+
     emit("\n## M.apply, second pass: collapse n -> n-1 qubits (read all, write half); then Insert back n-1 -> n")
     for bit in (0, 2, 5, 6, 12, 20, n - 1):
         q = n - 1 - bit
