@@ -174,15 +174,71 @@ constexpr int MAX_BLOCK = 32;
 // Blocks come in pairs (`pairs`: a large block with a small one, at most MAX_BLOCK elements together, second = -1 if
 // alone) that one workgroup handles one after the other: a beam splitter's 63 anti-diagonals of 1..32 elements become 32
 // work items of exactly 32 elements each, instead of 63 whose smallest move 16 bytes per thread.
-template <int THREADS, bool REALM>
+// The block matrix is stored with its rows padded to NC = 4 ceil(s / 4) entries (zeros), and the row loop is compiled
+// for each NC without any guard inside: the row's coefficients are wave-uniform, so they arrive through a few wide
+// scalar loads issued together and feed the FMAs as SGPR operands.  (Round 2's first version guarded every column with
+// `c < s`; the compiler then issued one s_load_dwordx2 + s_waitcnt per pair of FMAs -- ~100 cycles of exposed scalar-cache
+// latency for 8 cycles of arithmetic, which is what the kernel's 7 ms were made of.)
+// Block elements that are a constant step apart in memory (a beam splitter's anti-diagonals, a two-mode squeezer's
+// diagonals) are addressed as first + c * step; arbitrary index sets go through the offset table, four entries at a time.
+template <int NC, bool REALM, bool NT, bool STRIDED>
+__device__ __forceinline__ void block_rows(amp_t *__restrict__ base, int s, const uint64_t *__restrict__ off,
+                                           uint64_t first, int64_t step, const double *__restrict__ M) {
+    amp_t x[NC];
+    if constexpr (STRIDED) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const amp_t *src = base + first + static_cast<int64_t>(c) * step;
+            if (c < NC - 3 || c < s) x[c] = NT ? __builtin_nontemporal_load(src) : *src;
+            else x[c] = amp_t{0.0, 0.0};
+        }
+    } else {
+#pragma unroll
+        for (int c0 = 0; c0 < NC; c0 += 4) {
+            uint64_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = off[c0 + j];   // the table is padded: reading past the block is safe
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j;
+                if (c < NC - 3 || c < s) x[c] = NT ? __builtin_nontemporal_load(base + o[j]) : base[o[j]];
+                else x[c] = amp_t{0.0, 0.0};
+            }
+        }
+    }
+    constexpr int RS = (REALM ? 1 : 2) * NC;   // doubles per matrix row
+    for (int row = 0; row < s; ++row) {
+        const double *mr = M + static_cast<size_t>(row) * RS;
+        amp_t acc = {0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if constexpr (REALM) {
+                acc.x = fma(mr[c], x[c].x, acc.x);
+                acc.y = fma(mr[c], x[c].y, acc.y);
+            } else {
+                acc = cfma(cplx{mr[2 * c], mr[2 * c + 1]}, x[c], acc);
+            }
+        }
+        amp_t *dst = STRIDED ? base + first + static_cast<int64_t>(row) * step : base + off[row];
+        if (NT) __builtin_nontemporal_store(acc, dst);
+        else *dst = acc;
+    }
+}
+
+// (The tables are separate `const * __restrict__` kernel arguments on purpose: only then does the compiler know that
+// nothing the kernel stores can alias them, which is what lets it fetch them through the scalar cache.)
+template <int THREADS, bool REALM, bool STRIDED>
 __global__ __launch_bounds__(THREADS) void k_mode2_blocks(amp_t *__restrict__ a, uint64_t L, int d, uint64_t Mid,
                                                          uint64_t R, int nblocks /* pairs */, uint64_t groups,
-                                                         const int32_t *__restrict__ pairs,
-                                                         const int32_t *__restrict__ sizes,
-                                                         const int64_t *__restrict__ mat_start,  // in complex entries
-                                                         const int32_t *__restrict__ idx_start,
-                                                         const uint64_t *__restrict__ plane_off,  // amplitude offsets
-                                                         const double *__restrict__ mats) {
+                                                         const int32_t *__restrict__ t_pairs,      // [2 * items], -1 = none
+                                                         const int32_t *__restrict__ t_sizes,      // [blocks]
+                                                         const int64_t *__restrict__ t_mat_start,  // [blocks] in doubles
+                                                         const int32_t *__restrict__ t_idx_start,  // [blocks]
+                                                         const uint64_t *__restrict__ t_plane_off,  // element offsets
+                                                         const uint64_t *__restrict__ t_first,     // [blocks] STRIDED
+                                                         const int64_t *__restrict__ t_step,       // [blocks] STRIDED
+                                                         const double *__restrict__ t_mats) {
+    constexpr bool NT = THREADS == QSV_BLOCK;   // contiguous plane groups touch every amplitude once: stream past the caches
     const uint64_t planes = L * Mid * R;
     const uint64_t items = (groups + 7) / 8 * 8 * nblocks;      // plane groups padded to a multiple of the 8 XCDs
     for (uint64_t w = blockIdx.x; w < items; w += gridDim.x) {
@@ -196,34 +252,23 @@ __global__ __launch_bounds__(THREADS) void k_mode2_blocks(amp_t *__restrict__ a,
         const uint64_t r = p % R, m = (p / R) % Mid, l = p / (R * Mid);
         amp_t *base = a + l * (R * d * Mid * d) + m * (R * d) + r;
         for (int half = 0; half < 2; ++half) {
-        const int b = pairs[2 * item + half];
-        if (b < 0) continue;
-        const int s = sizes[b];
-        const uint64_t *off = plane_off + idx_start[b];
-        const double *M = mats + (REALM ? 1 : 2) * mat_start[b];  // real matrices are stored as one double per entry
-        amp_t x[MAX_BLOCK];
-#pragma unroll
-        for (int c = 0; c < MAX_BLOCK; ++c) {
-            // contiguous plane groups touch every amplitude exactly once: stream past the caches
-            if (c < s) x[c] = THREADS == QSV_BLOCK ? __builtin_nontemporal_load(base + off[c]) : base[off[c]];
-            else x[c] = amp_t{0.0, 0.0};
-        }
-        for (int row = 0; row < s; ++row) {
-            const double *mr = M + (REALM ? 1 : 2) * static_cast<size_t>(row) * s;
-            amp_t acc = {0.0, 0.0};
-#pragma unroll
-            for (int c = 0; c < MAX_BLOCK; ++c)
-                if (c < s) {
-                    if constexpr (REALM) {
-                        acc.x = fma(mr[c], x[c].x, acc.x);
-                        acc.y = fma(mr[c], x[c].y, acc.y);
-                    } else {
-                        acc = cfma(cplx{mr[2 * c], mr[2 * c + 1]}, x[c], acc);
-                    }
-                }
-            if (THREADS == QSV_BLOCK) __builtin_nontemporal_store(acc, base + off[row]);
-            else base[off[row]] = acc;
-        }
+            const int b = t_pairs[2 * item + half];
+            if (b < 0) continue;
+            const int s = t_sizes[b];
+            const uint64_t *off = t_plane_off + t_idx_start[b];
+            const double *M = t_mats + t_mat_start[b];
+            const uint64_t first = STRIDED ? t_first[b] : 0;
+            const int64_t step = STRIDED ? t_step[b] : 0;
+            switch ((s + 3) >> 2) {
+            case 1: block_rows<4, REALM, NT, STRIDED>(base, s, off, first, step, M); break;
+            case 2: block_rows<8, REALM, NT, STRIDED>(base, s, off, first, step, M); break;
+            case 3: block_rows<12, REALM, NT, STRIDED>(base, s, off, first, step, M); break;
+            case 4: block_rows<16, REALM, NT, STRIDED>(base, s, off, first, step, M); break;
+            case 5: block_rows<20, REALM, NT, STRIDED>(base, s, off, first, step, M); break;
+            case 6: block_rows<24, REALM, NT, STRIDED>(base, s, off, first, step, M); break;
+            case 7: block_rows<28, REALM, NT, STRIDED>(base, s, off, first, step, M); break;
+            default: block_rows<32, REALM, NT, STRIDED>(base, s, off, first, step, M); break;
+            }
         }
     }
 }
@@ -655,10 +700,35 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
         const int rc_plane = launch_plane(st, d, L, nblocks, sizes, mat_start, idx_start, off, mats);
         if (rc_plane != QSV_UNHANDLED) return rc_plane;
     }
-    std::vector<double> real_mats;
-    if (real) {  // one double per entry
-        real_mats.resize(mtot);
-        for (int64_t i = 0; i < mtot; ++i) real_mats[i] = mats[2 * i];
+    // padded matrices: row stride 4 ceil(s / 4) entries, one double per entry when every block is real
+    std::vector<int64_t> pad_start(nblocks);
+    int64_t ptot = 0;
+    const int per = real ? 1 : 2;
+    for (int k = 0; k < nblocks; ++k) {
+        pad_start[k] = ptot;
+        ptot += static_cast<int64_t>(per) * sizes[k] * ((sizes[k] + 3) / 4 * 4);
+    }
+    std::vector<double> pad_mats(ptot + 2 * MAX_BLOCK, 0.0);
+    for (int k = 0; k < nblocks; ++k) {
+        const int sz = sizes[k], s4 = (sz + 3) / 4 * 4;
+        for (int r = 0; r < sz; ++r)
+            for (int c = 0; c < sz; ++c) {
+                const double *src = mats + 2 * (mat_start[k] + static_cast<int64_t>(r) * sz + c);
+                double *dst = pad_mats.data() + pad_start[k] + static_cast<int64_t>(per) * (r * s4 + c);
+                dst[0] = src[0];
+                if (!real) dst[1] = src[1];
+            }
+    }
+    // constant step between the elements of every block?
+    bool strided = true;
+    std::vector<uint64_t> first(nblocks);
+    std::vector<int64_t> step(nblocks, 0);
+    for (int k = 0; k < nblocks && strided; ++k) {
+        const uint64_t *o = off.data() + idx_start[k];
+        first[k] = o[0];
+        if (sizes[k] > 1) step[k] = static_cast<int64_t>(o[1]) - static_cast<int64_t>(o[0]);
+        for (int c = 2; c < sizes[k] && strided; ++c)
+            strided = static_cast<int64_t>(o[c]) - static_cast<int64_t>(o[c - 1]) == step[k];
     }
     // pair blocks: largest with the smallest that still fits MAX_BLOCK elements together
     std::vector<int> order(nblocks);
@@ -671,28 +741,38 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
         else pairs.push_back(-1);
     }
     const int nitems = static_cast<int>(pairs.size() / 2);
-    // one device buffer: [mats | plane_off | mat_start | sizes | idx_start | pairs], every section 16-byte aligned
+    // one device buffer: [mats | plane_off | first | step | mat_start | sizes | idx_start | pairs], sections 16-byte aligned
     auto pad16 = [](size_t x) { return (x + 15) / 16 * 16; };
-    const size_t b_m = pad16(sizeof(double) * 2 * mtot), b_o = pad16(sizeof(uint64_t) * off.size()),
-                 b_s = pad16(sizeof(int64_t) * nblocks), b_z = pad16(sizeof(int32_t) * nblocks);
-    const size_t b_p = pad16(sizeof(int32_t) * pairs.size());
-    int rc = qsvk_ensure_matrix(st, b_m + b_o + b_s + 2 * b_z + b_p);
+    struct Section { const void *src; size_t bytes; size_t at; };
+    Section sec[8] = {{pad_mats.data(), sizeof(double) * pad_mats.size(), 0},
+                      {off.data(), sizeof(uint64_t) * off.size(), 0},
+                      {first.data(), sizeof(uint64_t) * nblocks, 0},
+                      {step.data(), sizeof(int64_t) * nblocks, 0},
+                      {pad_start.data(), sizeof(int64_t) * nblocks, 0},
+                      {sizes, sizeof(int32_t) * nblocks, 0},
+                      {idx_start.data(), sizeof(int32_t) * nblocks, 0},
+                      {pairs.data(), sizeof(int32_t) * pairs.size(), 0}};
+    size_t total = 0;
+    for (auto &x : sec) {
+        x.at = total;
+        total += pad16(x.bytes);
+    }
+    int rc = qsvk_ensure_matrix(st, total);
     if (rc) return rc;
+    // one staging image, one copy
+    std::vector<char> image(total, 0);
+    for (auto &x : sec) memcpy(image.data() + x.at, x.src, x.bytes);
     char *p = reinterpret_cast<char *>(st->dev_matrix);
-    double *d_m = reinterpret_cast<double *>(p);
-    uint64_t *d_o = reinterpret_cast<uint64_t *>(p + b_m);
-    int64_t *d_s = reinterpret_cast<int64_t *>(p + b_m + b_o);
-    int32_t *d_z = reinterpret_cast<int32_t *>(p + b_m + b_o + b_s);
-    int32_t *d_i = reinterpret_cast<int32_t *>(p + b_m + b_o + b_s + b_z);
-    int32_t *d_p = reinterpret_cast<int32_t *>(p + b_m + b_o + b_s + 2 * b_z);
-    if (real) QSV_HIP(hipMemcpyAsync(d_m, real_mats.data(), sizeof(double) * mtot, hipMemcpyHostToDevice, st->stream));
-    else QSV_HIP(hipMemcpyAsync(d_m, mats, sizeof(double) * 2 * mtot, hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipMemcpyAsync(d_o, off.data(), sizeof(uint64_t) * off.size(), hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipMemcpyAsync(d_s, mat_start.data(), sizeof(int64_t) * nblocks, hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipMemcpyAsync(d_z, sizes, sizeof(int32_t) * nblocks, hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipMemcpyAsync(d_i, idx_start.data(), sizeof(int32_t) * nblocks, hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipMemcpyAsync(d_p, pairs.data(), sizeof(int32_t) * pairs.size(), hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipStreamSynchronize(st->stream));  // all sources are pageable host memory that dies at return
+    QSV_HIP(hipMemcpyAsync(p, image.data(), total, hipMemcpyHostToDevice, st->stream));
+    QSV_HIP(hipStreamSynchronize(st->stream));  // the source is pageable host memory that dies at return
+    const double *t_mats = reinterpret_cast<const double *>(p + sec[0].at);
+    const uint64_t *t_off = reinterpret_cast<const uint64_t *>(p + sec[1].at);
+    const uint64_t *t_first = reinterpret_cast<const uint64_t *>(p + sec[2].at);
+    const int64_t *t_step = reinterpret_cast<const int64_t *>(p + sec[3].at);
+    const int64_t *t_start = reinterpret_cast<const int64_t *>(p + sec[4].at);
+    const int32_t *t_sizes = reinterpret_cast<const int32_t *>(p + sec[5].at);
+    const int32_t *t_idx = reinterpret_cast<const int32_t *>(p + sec[6].at);
+    const int32_t *t_pairs = reinterpret_cast<const int32_t *>(p + sec[7].at);
     const uint64_t planes = L * Mid * R;
     // R >= 8: a 128-byte line holds amplitudes of one plane point only, so every line is touched by exactly one block
     // (stream, nontemporal).  R < 8: lines are shared by up to 8 anti-diagonals; one wave per workgroup keeps a plane
@@ -701,22 +781,24 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
     const uint64_t groups = (planes + threads - 1) / threads;
     const uint64_t items = (groups + 7) / 8 * 8 * nitems;
     const unsigned grid = static_cast<unsigned>(items < 0x00ffffffull ? items : 0x00ffffffull);
-    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_mode2_blocks<%d, %s>", threads, real ? "true" : "false");
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_mode2_blocks<%d, %s, %s>", threads, real ? "true" : "false",
+             strided ? "true" : "false");
+    const int di = static_cast<int>(d);
+#define QSV_LAUNCH_BLOCKS(T, RM, SD)                                                                                   \
+    hipLaunchKernelGGL((k_mode2_blocks<T, RM, SD>), dim3(grid), dim3(T), 0, st->stream, st->data, L, di, Mid, R, nitems, \
+                       groups, t_pairs, t_sizes, t_start, t_idx, t_off, t_first, t_step, t_mats)
     if (threads == QSV_BLOCK) {
-        if (real)
-            hipLaunchKernelGGL((k_mode2_blocks<QSV_BLOCK, true>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, L,
-                               static_cast<int>(d), Mid, R, nitems, groups, d_p, d_z, d_s, d_i, d_o, d_m);
-        else
-            hipLaunchKernelGGL((k_mode2_blocks<QSV_BLOCK, false>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, L,
-                               static_cast<int>(d), Mid, R, nitems, groups, d_p, d_z, d_s, d_i, d_o, d_m);
+        if (real && strided) QSV_LAUNCH_BLOCKS(QSV_BLOCK, true, true);
+        else if (real) QSV_LAUNCH_BLOCKS(QSV_BLOCK, true, false);
+        else if (strided) QSV_LAUNCH_BLOCKS(QSV_BLOCK, false, true);
+        else QSV_LAUNCH_BLOCKS(QSV_BLOCK, false, false);
     } else {
-        if (real)
-            hipLaunchKernelGGL((k_mode2_blocks<64, true>), dim3(grid), dim3(64), 0, st->stream, st->data, L,
-                               static_cast<int>(d), Mid, R, nitems, groups, d_p, d_z, d_s, d_i, d_o, d_m);
-        else
-            hipLaunchKernelGGL((k_mode2_blocks<64, false>), dim3(grid), dim3(64), 0, st->stream, st->data, L,
-                               static_cast<int>(d), Mid, R, nitems, groups, d_p, d_z, d_s, d_i, d_o, d_m);
+        if (real && strided) QSV_LAUNCH_BLOCKS(64, true, true);
+        else if (real) QSV_LAUNCH_BLOCKS(64, true, false);
+        else if (strided) QSV_LAUNCH_BLOCKS(64, false, true);
+        else QSV_LAUNCH_BLOCKS(64, false, false);
     }
+#undef QSV_LAUNCH_BLOCKS
     return check_launch();
 }
 

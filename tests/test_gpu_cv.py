@@ -248,7 +248,7 @@ def test_fock_path_cfg4_at_cutoff_32(n_modes, plane_kernel):
         want = CO.apply_two_axes(want, bs, *pair)
         assert maxdiff(st.contract(), want) < 1e-12, pair
         if max(pair) == n_modes - 1:
-            assert st.reg.last_kernel().startswith("k_mode2_plane<" if plane_kernel else "k_mode2_blocks<64, true>")
+            assert st.reg.last_kernel().startswith("k_mode2_plane<" if plane_kernel else "k_mode2_blocks<64, true")
     # a beam splitter with a phase has complex blocks (the real-matrix fast paths must not be taken for it)
     bs_c = fock.beamsplitter_blocks(d, 0.4, 0.9)
     st.reg.apply_two_mode_blocks(bs_c, n_modes - 2, n_modes - 1)
@@ -282,7 +282,7 @@ def test_block_operator_on_the_last_two_modes(n_modes, d):
             m[np.ix_(idx, idx)] = block
         want = CO.apply_two_axes(want, m, *legs)
         assert maxdiff(st.to_numpy(), want) < 1e-12, (legs, len(blocks))
-    expect = "k_mode2_plane<" if d != 12 else "k_mode2_blocks<64, true>"
+    expect = "k_mode2_plane<" if d != 12 else "k_mode2_blocks<64, true"
     assert all(k.startswith(expect) for k in kernels), kernels
     # unequal spacing inside a block: not the plane kernel's case
     idx = [0, 1, d + 2, 2 * d + 1][: min(4, d)]

@@ -657,6 +657,16 @@ def test_sharded_state_on_one_gpu(world):
     assert f"dist_worker ok: world={world} backend=gloo-gpu" in out and "chunk_amps=64" in out
 
 
+def test_shipped_collectives_on_rccl_with_one_rank():
+    """RCCL refuses two ranks on one device; a one-rank world still runs the shipped ``_p2p`` (grouped ncclSend /
+    ncclRecv of (re, im) views of shard slices), all-reduce and all-gather on HBM tensors over the real backend."""
+    import subprocess
+    import sys
+    worker = Path(__file__).resolve().parent / "rccl_self_worker.py"
+    r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl self ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("n,world", [(30, 2), (32, 2), (31, 4)])
 def test_large_sharded_register_at_the_production_piece_size(n, world):
     """Two ranks on the one GPU with 8 GiB and 32 GiB shards (32 GiB is the shard of BASELINE config 3: 34 qubits on 8
