@@ -103,6 +103,7 @@ int qsvk_pair_exchange(qsv_state *st, int bit_a, int bit_b);  // SWAP on two hig
 int qsvk_diag(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits, const double *d_user);
 int qsvk_phase(qsv_state *st, int nctrl, const int *cbits, double re, double im);
 int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user);
+constexpr int QSV_UNHANDLED_KQ = 1 << 20;  // internal: "not this kernel's case"
 int qsvk_measure_probs(qsv_state *st, int bit, const double eig0[4], const double eig1[4], double *p0, double *p1);
 int qsvk_collapse(qsv_state *st, int bit, const double eig[4], double scale);
 int qsvk_insert(qsv_state *st, int bit, const double amp[4]);

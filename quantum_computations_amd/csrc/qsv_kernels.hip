@@ -1438,6 +1438,93 @@ static void launch_big_kernel(qsv_state *st, bool nt, dim3 gd, const BigArgs &g,
     else hipLaunchKernelGGL((k_dense_big<K, KL, false>), gd, bd, 0, st->stream, st->data, g, st->dev_matrix, dev_off);
 }
 
+// ---- k-qubit dense gate, targets on bits >= 3, staged through LDS: "tile" form -------------------------------------
+// k_dense_big gives every thread a whole 2^K-amplitude column (128 VGPRs at K = 5: two or three waves per SIMD that
+// load, compute and store in lock step).  Here a workgroup of 2^K / ROWS waves owns 64 columns: wave q loads inputs
+// q ROWS .. q ROWS + ROWS - 1 of every column (1 KiB per wave-instruction: the 64 columns are the 64 lowest free index
+// values, so lanes 8j..8j+7 cover one whole 128-byte line whatever the target bits >= 3 are), parks them in a
+// [2^K][64] LDS tile, and after one barrier computes outputs q ROWS .. q ROWS + ROWS - 1 of its lane's column: the 2^K
+// inputs come back from LDS one 16-byte read each (lane-contiguous, conflict-free), the ROWS x 2^K slice of the matrix
+// is wave-uniform and arrives as SGPR operands.  ROWS accumulators instead of 2^K amplitudes per thread: five
+// workgroups per CU (LDS-bound at K = 5), whose load / compute / store phases overlap.
+template <int K, int ROWS, bool REAL, bool NT>
+__global__ __launch_bounds__((1 << K) / ROWS * 64) void k_dense_tile(amp_t *__restrict__ a, const BigArgs g,
+                                                                     const double *__restrict__ mat,   // [q][c][ROWS]
+                                                                     const uint64_t *__restrict__ off) {
+    constexpr int D = 1 << K;
+    __shared__ amp_t tile[D * 64];
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // tile order as in k_dense: `regions` contiguous pieces of this launch's range walked side by side
+    const uint64_t tile_id = (g.regions > 1 && gridDim.x % g.regions == 0)
+                                 ? (blockIdx.x % g.regions) * (gridDim.x / g.regions) + blockIdx.x / g.regions
+                                 : blockIdx.x;
+    const uint64_t base = deposit(g.w0 + tile_id * 64 + lane, g);
+    uint64_t o[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) o[i] = off[q * ROWS + i];
+    {
+        amp_t x[ROWS];
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) x[i] = NT ? __builtin_nontemporal_load(a + base + o[i]) : a[base + o[i]];
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) tile[(q * ROWS + i) * 64 + lane] = x[i];
+    }
+    __syncthreads();
+    amp_t acc[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) acc[i] = amp_t{0.0, 0.0};
+    const double *m = mat + static_cast<size_t>(q) * D * ROWS * (REAL ? 1 : 2);
+#pragma unroll 8
+    for (int c = 0; c < D; ++c) {
+        const amp_t v = tile[c * 64 + lane];
+        const double *mc = m + c * ROWS * (REAL ? 1 : 2);
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            if constexpr (REAL) {
+                acc[i].x = fma(mc[i], v.x, acc[i].x);
+                acc[i].y = fma(mc[i], v.y, acc[i].y);
+            } else {
+                acc[i] = cfma(cplx{mc[2 * i], mc[2 * i + 1]}, v, acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        if (NT) __builtin_nontemporal_store(acc[i], a + base + o[i]);
+        else a[base + o[i]] = acc[i];
+    }
+}
+
+template <int K, int ROWS>
+static int launch_tile_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const BigArgs &g, const uint64_t *dev_off) {
+    const double *m = st->dev_matrix;
+    const dim3 bd((1 << K) / ROWS * 64);
+    if (nt) {
+        if (realm) hipLaunchKernelGGL((k_dense_tile<K, ROWS, true, true>), gd, bd, 0, st->stream, st->data, g, m, dev_off);
+        else hipLaunchKernelGGL((k_dense_tile<K, ROWS, false, true>), gd, bd, 0, st->stream, st->data, g, m, dev_off);
+    } else {
+        if (realm) hipLaunchKernelGGL((k_dense_tile<K, ROWS, true, false>), gd, bd, 0, st->stream, st->data, g, m, dev_off);
+        else hipLaunchKernelGGL((k_dense_tile<K, ROWS, false, false>), gd, bd, 0, st->stream, st->data, g, m, dev_off);
+    }
+    return check_launch();
+}
+
+// Tile order of k_dense_tile by target placement (MI355X, n = 28 and 30, profiles/r02_tile_order.txt).  Which DRAM
+// channels the workgroups in flight hit together depends on the target bits; no single order wins everywhere:
+// contiguous windows (the d = 2^K modes of the CV path) have a clear best order per position, scattered targets
+// (fused qubit gates) are served well by 2 regions (K = 4) / 8 regions (K = 5).
+static uint32_t tile_regions(int k, const std::vector<int> &sorted_bits) {
+    const int lo = sorted_bits.front(), top = sorted_bits.back();
+    const bool window = top - lo == static_cast<int>(sorted_bits.size()) - 1;
+    if (k == 4) {
+        if (!window) return 2;
+        return top <= 10 ? 4 : top <= 15 ? 2 : top <= 19 ? 0 : top == 20 ? 2 : top <= 23 ? 8 : 2;
+    }
+    if (!window) return 8;
+    return top <= 11 ? 8 : top <= 13 ? 4 : top <= 20 ? 0 : 2;
+}
+
 template <int K>
 static int dispatch_big(qsv_state *st, int KL, bool nt, dim3 gd, const BigArgs &g, const uint64_t *dev_off) {
     switch (KL) {
@@ -1456,7 +1543,6 @@ static int dispatch_big(qsv_state *st, int KL, bool nt, dim3 gd, const BigArgs &
 }
 
 
-constexpr int QSV_UNHANDLED_KQ = 1 << 20;  // internal: "not this kernel's case, take the gather kernel"
 
 template <int K, int KB, int BLOCK>
 static void launch_lds_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const LdsArgs &g, const uint64_t *dev_off) {
@@ -1492,7 +1578,15 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     std::vector<int> standin;
     for (int b = QSV_LANE_BITS; b < st->n && static_cast<int>(standin.size()) < KL; ++b)
         if (std::find(high.begin(), high.end(), b) == high.end()) standin.push_back(b);
-    const bool transposed = KL > 0 && static_cast<int>(standin.size()) == KL && st->kq_variant != 2;
+    bool all_from_bit3 = true;
+    for (int j = 0; j < k; ++j) all_from_bit3 = all_from_bit3 && bits[j] >= 3;
+    const bool tile_ok = (k == 4 || k == 5) && all_from_bit3 && (st->amps >> k) >= 64 && (st->amps >> k) % 64 == 0;
+    bool real_matrix = true;
+    for (int i = 0; i < D * D && real_matrix; ++i) real_matrix = m_user[2 * i + 1] == 0.0;
+    // shipped choice: k = 4, and k = 5 with a real matrix (a complex 32 x 32 product per column keeps the FP64 pipe busy
+    // for 0.9 of the 1.4 ms the memory traffic takes; the tile form's extra LDS round trip then costs more than it hides)
+    const bool use_tile = tile_ok && (st->kq_variant == 4 || (st->kq_variant == 0 && (k == 4 || real_matrix)));
+    const bool transposed = KL > 0 && static_cast<int>(standin.size()) == KL && st->kq_variant != 2 && !use_tile;
     if (!transposed) {  // all targets high, or a register too small to transpose: lanes = lowest free bits
         high.assign(bits, bits + k);
         low.clear();
@@ -1500,14 +1594,12 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
         KL = 0;
     }
     const int KH = k - KL;
-    bool real_matrix = true;
-    for (int i = 0; i < D * D && real_matrix; ++i) real_matrix = m_user[2 * i + 1] == 0.0;
     // Which form (MI355X, n = 28, profiles/r02_sweep_kq_kernels.txt): k = 5 with low targets -> the line-granular
     // kernel (4.9-5.2 TB/s at every placement; the shuffle form drops to 2.1-4.4 there); k = 5 real matrices ->
     // the same kernel's two-FMA arithmetic (5.4-5.8 TB/s); k = 3, 4 and k = 5 on high bits -> the shuffle form
     // (its butterflies are cheap up to 16 amplitudes per thread: 5.6-6.0 TB/s).  QSV_OPT_KQ_VARIANT overrides.
     const bool fits = (st->amps >> k) >= 64 && (st->amps >> k) % 64 == 0;
-    const bool use_lds = fits && (k == 6 || st->kq_variant == 3 ||
+    const bool use_lds = !use_tile && fits && (k == 6 || st->kq_variant == 3 ||
                                   (st->kq_variant == 0 && k == 5 && (KL > 0 || real_matrix)));
     if (k == 6 && !use_lds) return QSV_UNHANDLED_KQ;  // only the line-granular kernel is built for 64 x 64 matrices
     int KB = 0;
@@ -1532,7 +1624,7 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
         }
         return u;
     };
-    const bool realm = use_lds && real_matrix;
+    const bool realm = (use_lds || use_tile) && real_matrix;
     std::vector<double> m(realm ? static_cast<size_t>(D) * D : 2ull * D * D);
     for (int r = 0; r < D; ++r)
         for (int c = 0; c < D; ++c) {
@@ -1555,6 +1647,34 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     ins.insert(ins.end(), standin.begin(), standin.end());
     std::sort(ins.begin(), ins.end());
     const uint64_t W = st->amps >> k;
+    if (use_tile) {
+        // matrix slice of wave q, input c: ROWS consecutive entries  [q][c][i] = m[q ROWS + i][c]
+        const int rows = k == 5 ? 8 : 4, per = realm ? 1 : 2;
+        std::vector<double> mt(m.size());
+        for (int r = 0; r < D; ++r)
+            for (int c = 0; c < D; ++c)
+                for (int e = 0; e < per; ++e)
+                    mt[per * ((static_cast<size_t>(r / rows) * D + c) * rows + r % rows) + e] = m[per * (r * D + c) + e];
+        QSV_HIP(hipMemcpyAsync(st->dev_matrix, mt.data(), sizeof(double) * mt.size(), hipMemcpyHostToDevice, st->stream));
+        QSV_HIP(hipStreamSynchronize(st->stream));
+        BigArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.W = W;
+        g.nins = static_cast<int>(ins.size());
+        for (size_t j = 0; j < ins.size(); ++j) g.pos[j] = static_cast<uint32_t>(ins[j]);
+        const bool nt = st->nontemporal != 0;  // every wave-instruction touches whole 128-byte lines
+        g.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : tile_regions(k, ins);
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_tile<%d, %d, %s, %s>", k, rows, realm ? "true" : "false",
+                 nt ? "true" : "false");
+        const uint64_t per_launch = 0x00ffffffull * 64;  // columns per dispatch
+        for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
+            const dim3 gd(static_cast<unsigned>(std::min(per_launch, g.W - g.w0) / 64));
+            const int rc2 = k == 5 ? launch_tile_kernel<5, 8>(st, nt, realm, gd, g, dev_off)
+                                   : launch_tile_kernel<4, 4>(st, nt, realm, gd, g, dev_off);
+            if (rc2) return rc2;
+        }
+        return QSV_OK;
+    }
     if (use_lds) {
         LdsArgs g;
         std::memset(&g, 0, sizeof(g));

@@ -249,6 +249,8 @@ def test_fock_path_cfg4_at_cutoff_32(n_modes, plane_kernel):
         assert maxdiff(st.contract(), want) < 1e-12, pair
         if max(pair) == n_modes - 1:
             assert st.reg.last_kernel().startswith("k_mode2_plane<" if plane_kernel else "k_mode2_blocks<64, true")
+        else:
+            assert st.reg.last_kernel().startswith("k_mode2_blocks<256, true, true>"), st.reg.last_kernel()
     # a beam splitter with a phase has complex blocks (the real-matrix fast paths must not be taken for it)
     bs_c = fock.beamsplitter_blocks(d, 0.4, 0.9)
     st.reg.apply_two_mode_blocks(bs_c, n_modes - 2, n_modes - 1)

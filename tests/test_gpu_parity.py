@@ -269,14 +269,14 @@ def test_six_qubit_gates_on_the_matrix_cores():
         assert maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL, bits
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("k", [3, 4, 5])
 def test_register_blocked_kq_every_low_target_set(k, variant):
     """k = 3..5 dense gates with EVERY set of target bits below 6 (all subsets of the six lane bits, up to k of them),
     the other legs on random high bits, legs in any order, complex and real matrices.  ``variant`` 3 is the
     line-granular kernel (k_dense_lds: address arithmetic for lane bits 3..5, LDS for bits 0..2), 1 the wave-shuffle
-    form (k_dense_big<K, KL>), 2 the no-exchange form, 0 the shipped per-case choice between them: all must agree
-    with the oracle."""
+    form (k_dense_big<K, KL>), 2 the no-exchange form, 4 the workgroup tile staged through LDS (k_dense_tile: k = 4, 5 with every target on bit 3
+    or higher), 0 the shipped per-case choice between them: all must agree with the oracle."""
     import itertools
 
     from quantum_computations_amd import _lib
@@ -308,6 +308,8 @@ def test_register_blocked_kq_every_low_target_set(k, variant):
         assert {name.split(", ")[3] for name in kernels} == {"true>", "false>"}      # real and complex matrices
     elif variant == 1:
         assert {name.split(", ")[1] for name in kernels} == {str(j) for j in range(k + 1)}, kernels
+    elif variant == 4:
+        assert any(name.startswith(f"k_dense_tile<{k}, ") for name in kernels) == (k >= 4), kernels
     else:
         assert kernels == {f"k_dense_big<{k}, 0, false>"} or kernels == {f"k_dense_big<{k}, 0, true>",
                                                                         f"k_dense_big<{k}, 0, false>"}, kernels

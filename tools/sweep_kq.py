@@ -69,12 +69,12 @@ def main():
             sets["5 low (b0..b4) = last d=32 mode"] = [0, 1, 2, 3, 4]
             sets["5 low (b1..b5)"] = [1, 2, 3, 4, 5]
             sets["mode 4 of 6 (b5..b9)"] = [5, 6, 7, 8, 9]
-        emit(f"\n## k = {k}: ms / GB/s per target-bit set; columns: variant 3 complex | variant 3 real | variant 1 | variant 2 | shipped choice complex | shipped choice real")
+        emit(f"\n## k = {k}: ms / GB/s per target-bit set; columns: variant 3 complex | variant 3 real | variant 1 | variant 2 | variant 4 (tile) complex | variant 4 real | shipped choice complex | shipped choice real")
         for label, bits in sets.items():
             qs = [n - 1 - b for b in bits]
             cells = []
             name0 = ""
-            for variant, u in ((3, uc), (3, ur), (1, uc), (2, uc), (0, uc), (0, ur)):
+            for variant, u in ((3, uc), (3, ur), (1, uc), (2, uc), (4, uc), (4, ur), (0, uc), (0, ur)):
                 dev.set_option(_lib.OPT_KQ_VARIANT, variant)
                 ms = timed(dev, lambda: dev.apply_matrix(u, qs), args.reps)
                 cells.append(f"{ms:7.3f} ms {gbytes / (ms * 1e-3):6.0f}")
