@@ -1513,10 +1513,14 @@ static int launch_tile_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const
 // Tile order of k_dense_tile by target placement (MI355X, n = 28 and 30, profiles/r02_tile_order.txt).  Which DRAM
 // channels the workgroups in flight hit together depends on the target bits; no single order wins everywhere:
 // contiguous windows (the d = 2^K modes of the CV path) have a clear best order per position, scattered targets
-// (fused qubit gates) are served well by 2 regions (K = 4) / 8 regions (K = 5).
+// (fused qubit gates) are served well by 4 regions (K = 3) / 2 (K = 4) / 8 (K = 5).
 static uint32_t tile_regions(int k, const std::vector<int> &sorted_bits) {
     const int lo = sorted_bits.front(), top = sorted_bits.back();
     const bool window = top - lo == static_cast<int>(sorted_bits.size()) - 1;
+    if (k == 3) {
+        if (!window) return 4;
+        return top <= 8 ? 4 : top <= 19 ? 2 : top <= 22 ? 8 : top <= 24 ? 2 : 0;
+    }
     if (k == 4) {
         if (!window) return 2;
         return top <= 10 ? 4 : top <= 15 ? 2 : top <= 19 ? 0 : top == 20 ? 2 : top <= 23 ? 8 : 2;
@@ -1580,12 +1584,12 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
         if (std::find(high.begin(), high.end(), b) == high.end()) standin.push_back(b);
     bool all_from_bit3 = true;
     for (int j = 0; j < k; ++j) all_from_bit3 = all_from_bit3 && bits[j] >= 3;
-    const bool tile_ok = (k == 4 || k == 5) && all_from_bit3 && (st->amps >> k) >= 64 && (st->amps >> k) % 64 == 0;
+    const bool tile_ok = k >= 3 && k <= 5 && all_from_bit3 && (st->amps >> k) >= 64 && (st->amps >> k) % 64 == 0;
     bool real_matrix = true;
     for (int i = 0; i < D * D && real_matrix; ++i) real_matrix = m_user[2 * i + 1] == 0.0;
-    // shipped choice: k = 4, and k = 5 with a real matrix (a complex 32 x 32 product per column keeps the FP64 pipe busy
+    // shipped choice: k = 3, 4, and k = 5 with a real matrix (a complex 32 x 32 product per column keeps the FP64 pipe busy
     // for 0.9 of the 1.4 ms the memory traffic takes; the tile form's extra LDS round trip then costs more than it hides)
-    const bool use_tile = tile_ok && (st->kq_variant == 4 || (st->kq_variant == 0 && (k == 4 || real_matrix)));
+    const bool use_tile = tile_ok && (st->kq_variant == 4 || (st->kq_variant == 0 && (k <= 4 || real_matrix)));
     const bool transposed = KL > 0 && static_cast<int>(standin.size()) == KL && st->kq_variant != 2 && !use_tile;
     if (!transposed) {  // all targets high, or a register too small to transpose: lanes = lowest free bits
         high.assign(bits, bits + k);
@@ -1649,7 +1653,7 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     const uint64_t W = st->amps >> k;
     if (use_tile) {
         // matrix slice of wave q, input c: ROWS consecutive entries  [q][c][i] = m[q ROWS + i][c]
-        const int rows = k == 5 ? 8 : 4, per = realm ? 1 : 2;
+        const int rows = k == 5 ? 8 : k == 4 ? 4 : 2, per = realm ? 1 : 2;
         std::vector<double> mt(m.size());
         for (int r = 0; r < D; ++r)
             for (int c = 0; c < D; ++c)
@@ -1670,7 +1674,8 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
         for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
             const dim3 gd(static_cast<unsigned>(std::min(per_launch, g.W - g.w0) / 64));
             const int rc2 = k == 5 ? launch_tile_kernel<5, 8>(st, nt, realm, gd, g, dev_off)
-                                   : launch_tile_kernel<4, 4>(st, nt, realm, gd, g, dev_off);
+                          : k == 4 ? launch_tile_kernel<4, 4>(st, nt, realm, gd, g, dev_off)
+                                   : launch_tile_kernel<3, 2>(st, nt, realm, gd, g, dev_off);
             if (rc2) return rc2;
         }
         return QSV_OK;

@@ -18,7 +18,7 @@ def timed(dev, fn, reps=8):
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 dev = DeviceState.random(n, 1)
 rng = np.random.default_rng(0)
-for k, real in ((4, False), (5, True)):
+for k, real in ((3, False),) if len(sys.argv) > 2 else ((4, False), (5, True)):
     u = np.linalg.qr(rng.standard_normal((1 << k, 1 << k)))[0] if real else W.haar_unitary(1 << k, rng)
     print(f"# k={k} {'real' if real else 'complex'}: start bit: shipped | tile regions 0, 1 (scrambled), 2, 4, 8", flush=True)
     for s in range(3, n - k + 1):
