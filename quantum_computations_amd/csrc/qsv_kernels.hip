@@ -1043,13 +1043,14 @@ struct RdmArgs {
 // of the tile are shared by S = 16 / 2^k groups (row i = r + 2^k s): every lane still loads a different amplitude, the
 // tile then holds S x S blocks of which only the S diagonal ones (same group on both sides) mean anything; the host adds
 // those up.
-constexpr int RDM_U = 4;
+constexpr int RDM_LOADS = 4;   // 16-byte loads per lane and buffer: RDM_LOADS / T quads of groups
 
 template <int T>
 __global__ __launch_bounds__(QSV_BLOCK) void k_rdm(const amp_t *__restrict__ a, const RdmArgs g,
                                                    const uint64_t *__restrict__ hoff,  // [16 T] row offsets
                                                    double *__restrict__ partials) {    // [grid][P][2][256]
     constexpr int P = T * (T + 1) / 2;
+    constexpr int RDM_U = RDM_LOADS / T;
     __shared__ double red[P * 2 * 256];
     const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     const int S = T == 1 ? 16 / g.D : 1;                 // groups sharing the 16 rows of a tile (D = 1 never occurs)
@@ -1059,30 +1060,26 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_rdm(const amp_t *__restrict__ a, 
     for (int t = 0; t < T; ++t) row_off[t] = hoff[T == 1 ? i % g.D : 16 * t + i];
     // C independent accumulator sets: consecutive MFMAs never wait for one another's result (with one set per tile
     // pair the two updates of `re` and of `im` in a step are back-to-back dependent issues of a 64-cycle instruction)
-    constexpr int C = T == 1 ? RDM_U : T == 2 ? 2 : 1;
+    constexpr int C = RDM_U >= 2 ? 2 : 1;
     f64x4 re[C][P], im[C][P];
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
         for (int p = 0; p < P; ++p) re[c][p] = im[c][p] = f64x4{0.0, 0.0, 0.0, 0.0};
-    const uint64_t steps = g.W / (4 * static_cast<uint64_t>(S));   // a step = 4 S groups = one MFMA k-slice per tile pair
+    // a step = 4 S groups = one MFMA k-slice per tile pair.  The host sizes the grid so that waves * RDM_U divides the
+    // step count: every load below is unconditional.
+    const uint64_t steps = g.W / (4 * static_cast<uint64_t>(S));
     const uint64_t wave = blockIdx.x * (QSV_BLOCK / 64) + (threadIdx.x >> 6);
-    const uint64_t waves = static_cast<uint64_t>(gridDim.x) * (QSV_BLOCK / 64);
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (QSV_BLOCK / 64) * RDM_U;
     auto fetch = [&](amp_t (&x)[RDM_U][T], uint64_t q0) {
 #pragma unroll
         for (int u = 0; u < RDM_U; ++u) {
             const uint64_t base = deposit<6>(((q0 + u) * 4 + kk) * S + sub, g);
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                x[u][t] = amp_t{0.0, 0.0};
-                if (q0 + u < steps) x[u][t] = __builtin_nontemporal_load(a + base + row_off[t]);
-            }
+            for (int t = 0; t < T; ++t) x[u][t] = __builtin_nontemporal_load(a + base + row_off[t]);
         }
     };
-    amp_t x[RDM_U][T], nxt[RDM_U][T];
-    fetch(x, wave * RDM_U);
-    for (uint64_t q0 = wave * RDM_U; q0 < steps; q0 += waves * RDM_U) {
-        fetch(nxt, q0 + waves * RDM_U);        // the next iteration's loads fly while this one's MFMAs run
+    auto update = [&](const amp_t (&x)[RDM_U][T]) {
         // first halves of every sum, then second halves: 2 C P independent instructions between dependent ones
 #pragma unroll
         for (int u = 0; u < RDM_U; ++u) {
@@ -1106,10 +1103,25 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_rdm(const amp_t *__restrict__ a, 
                     im[u % C][p] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[u][ti].x, x[u][tj].y, im[u % C][p], 0, 0, 0);
                 }
         }
-#pragma unroll
-        for (int u = 0; u < RDM_U; ++u)
-#pragma unroll
-            for (int t = 0; t < T; ++t) x[u][t] = nxt[u][t];
+    };
+    // two buffers, no copies between them: while one feeds the matrix cores the other one's loads are in flight, and the
+    // wait in front of the MFMAs is for the OLDER buffer only (a register copy at the loop end made the compiler wait for
+    // every outstanding load in the middle of the MFMAs: one buffer in flight per wave, 4.3 TB/s)
+    // Every fetch is unconditional (past the end a wave re-reads its first chunk and drops it): with loads under a
+    // branch the compiler cannot count how many younger loads are in flight and waits for all of them.
+    amp_t xa[RDM_U][T], xb[RDM_U][T];
+    const uint64_t first = wave * RDM_U;
+    uint64_t q0 = first;
+    fetch(xa, q0);
+    for (;;) {
+        q0 += stride;
+        fetch(xb, q0 < steps ? q0 : first);
+        update(xa);
+        if (q0 >= steps) break;
+        q0 += stride;
+        fetch(xa, q0 < steps ? q0 : first);
+        update(xb);
+        if (q0 >= steps) break;
     }
 #pragma unroll
     for (int c = 1; c < C; ++c)
@@ -2161,11 +2173,16 @@ int qsvk_reduced_density(qsv_state *st, int k, const int *bits, double *rho_out)
     g.D = D;
     for (int i = 0; i < k; ++i) g.pos[i] = static_cast<uint32_t>(sorted[i]);
     const int S = D < 16 ? 16 / D : 1;                   // groups sharing a 16-row tile (k_rdm)
-    const bool big = st->n >= RO_MIN_QUBITS && g.W % (4 * static_cast<uint64_t>(S)) == 0;
+    const bool big = st->n >= RO_MIN_QUBITS && g.W % (4ull * S * 4 * (RDM_LOADS / T)) == 0;  // whole iterations for >= one workgroup
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st->device);  // 256 if the query fails
-    const int blocks =
-        big ? static_cast<int>(std::min<uint64_t>((T <= 2 ? 4ull : 2ull) * cus, std::max<uint64_t>(1, g.W / (4ull * S) / (4 * RDM_U)))) : 0;
+    // a power-of-two grid, so that (waves in the grid) x RDM_U divides the (power-of-two) number of steps
+    int blocks = 0;
+    if (big) {
+        const uint64_t most = std::min<uint64_t>((T <= 2 ? 4ull : 2ull) * cus, std::max<uint64_t>(1, g.W / (4ull * S) / (4 * (RDM_LOADS / T))));
+        blocks = 1;
+        while (2ull * blocks <= most) blocks *= 2;
+    }
     const int entries = big ? P * 2 * 256 : 2 * D * D;
     const size_t b_off = sizeof(uint64_t) * off.size(), b_out = sizeof(double) * entries,
                  b_part = sizeof(double) * static_cast<size_t>(blocks) * entries;
