@@ -477,8 +477,9 @@ __global__ __launch_bounds__(BLOCK) void k_dense_lds(amp_t *__restrict__ a, cons
 // B[k = lane >> 4][j = lane & 15], D col = lane & 15, row = (lane >> 4) + 4 reg; same peak as the vector pipe, but 64
 // VGPRs of inputs per lane instead of 256, so two waves per SIMD overlap loads with arithmetic -- the register-blocked
 // vector form ran at 8.5 TFLOP/s, one wave per SIMD, stalled on its 1 KiB matrix rows).
-// A wave owns 16 consecutive groups (index bits 0..3 must not be targets; the launcher moves lower targets out of the
-// way with a qubit permutation before and after): lane (li, lk) holds amplitudes 4 s + lk, s = 0..15, of group li.
+// A wave owns 16 groups (the 16 lowest free index values): lane (li, lk) holds amplitudes 4 s + lk, s = 0..15, of group
+// li -- lk runs over the two lowest target bits, so whatever the targets are a wave-instruction touches whole 128-byte
+// lines (half lines when bits 0, 1 and 2 are all targets).
 // The matrix sits in LDS column-major (real and imaginary planes), a complex product is four real MFMAs, a real
 // matrix needs two.  Loads and stores are four 256-byte runs per wave-instruction: whole 128-byte lines.
 // ----------------------------------------------------------------------------------------------------
@@ -1753,25 +1754,11 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
 // k = 6 on the matrix cores (k_dense6_mfma).  bits[j] = bit position of matrix leg j (leg 0 most significant).
 static int launch_dense6(qsv_state *st, const int *bits, const double *m_user) {
     constexpr int D = 64;
-    // targets on index bits 0..3 would split a wave's 16 consecutive groups: trade them for free high bits with a
-    // qubit permutation (a product of disjoint transpositions, so the same permutation undoes it afterwards)
-    std::vector<int> tb(bits, bits + 6), perm(st->n);
-    for (int b = 0; b < st->n; ++b) perm[b] = b;
-    bool moved = false;
-    for (int j = 0; j < 6; ++j)
-        if (tb[j] < 4) {
-            int e = st->n - 1;
-            while (e >= 6 && (std::find(tb.begin(), tb.end(), e) != tb.end() || perm[e] != e)) --e;
-            if (e < 6) return qsv_fail(QSV_EINVAL, "6-qubit gate: the register is too small");
-            perm[e] = tb[j];
-            perm[tb[j]] = e;
-            tb[j] = e;
-            moved = true;
-        }
-    if (moved) {
-        const int rc = qsvk_permute(st, perm.data());
-        if (rc) return rc;
-    }
+    // A wave's 16 lanes li are the 16 lowest free index values and its 4 lanes lk the two lowest target bits, so a
+    // wave-instruction covers whole 128-byte lines wherever the targets sit, unless bits 0, 1 AND 2 are all targets
+    // (then it covers half lines, and the other half follows in the next instruction of the same wave): 2.9-3.1 ms at
+    // every placement.  (Round 2 first moved low targets away with a qubit permutation before and after: 6.2 ms.)
+    const std::vector<int> tb(bits, bits + 6);
     std::vector<int> sorted(tb);
     std::sort(sorted.begin(), sorted.end());
     // register / matrix index c: bit i <-> sorted[i]
@@ -1825,9 +1812,7 @@ static int launch_dense6(qsv_state *st, const int *bits, const double *m_user) {
     if (nt) { if (real_matrix) QSV_LAUNCH6(true, true); else QSV_LAUNCH6(true, false); }
     else { if (real_matrix) QSV_LAUNCH6(false, true); else QSV_LAUNCH6(false, false); }
 #undef QSV_LAUNCH6
-    rc = check_launch();
-    if (rc) return rc;
-    return moved ? qsvk_permute(st, perm.data()) : QSV_OK;
+    return check_launch();
 }
 
 int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user) {
