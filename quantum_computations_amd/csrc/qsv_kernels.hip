@@ -493,7 +493,7 @@ struct Mfma6Args {
 };
 
 template <bool NT, bool REALM>
-__global__ __launch_bounds__(QSV_BLOCK) void k_dense6_mfma(amp_t *__restrict__ a, const Mfma6Args g,
+__global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dense6_mfma(amp_t *__restrict__ a, const Mfma6Args g,
                                                            const double *__restrict__ Mcol,  // [plane][col][row]
                                                            const uint64_t *__restrict__ hoff) {
     extern __shared__ __attribute__((aligned(16))) char smem6[];
@@ -506,11 +506,14 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_dense6_mfma(amp_t *__restrict__ a
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const uint64_t wave = blockIdx.x * (QSV_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t waves = static_cast<uint64_t>(gridDim.x) * (QSV_BLOCK / 64);
-    for (uint64_t tile = wave; tile * 16 < g.W; tile += waves) {
+    const uint64_t tiles = g.W / 16;
+    if (wave >= tiles) return;
+    auto fetch = [&](amp_t (&x)[16], uint64_t tile) {
         const uint64_t base = deposit<6>(tile * 16 + li, g);
-        amp_t x[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) x[s] = ld<NT>(a + base + off[4 * s + lk]);
+    };
+    auto apply = [&](const amp_t (&x)[16], uint64_t tile) {
         f64x4 cre[4], cim[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) cre[t] = cim[t] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -534,13 +537,33 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_dense6_mfma(amp_t *__restrict__ a
                     cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[t], x[s].x, cim[t], 0, 0, 0);
                 }
             }
+            // keep the matrix reads of slice s + 1 behind the MFMAs of slice s: hoisted to the top (the scheduler's
+            // choice without this fence) the 16 slices' operands need 256 VGPRs and spill
+            __builtin_amdgcn_sched_barrier(0);
         }
         // in place: the wave has read every amplitude of its 16 groups before the first of these stores can issue
+        const uint64_t base = deposit<6>(tile * 16 + li, g);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 st<NT>(a + base + off[16 * t + lk + 4 * r], amp_t{cre[t][r], cim[t][r]});
+    };
+    // Two input buffers, no copies between them: the next tile's 16 loads are in flight while this tile's 256 (128)
+    // MFMAs run.  Every fetch is unconditional -- past the end a wave re-reads its first tile and drops it -- because the
+    // compiler cannot count loads issued under a branch and would wait for all of them (see k_rdm).
+    amp_t xa[16], xb[16];
+    uint64_t tile = wave;
+    fetch(xa, tile);
+    for (;;) {
+        const uint64_t t1 = tile + waves;
+        fetch(xb, t1 < tiles ? t1 : wave);
+        apply(xa, tile);
+        if (t1 >= tiles) break;
+        tile = t1 + waves;
+        fetch(xa, tile < tiles ? tile : wave);
+        apply(xb, t1);
+        if (tile >= tiles) break;
     }
 }
 
