@@ -1127,25 +1127,32 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_rdm(const amp_t *__restrict__ a, 
                     im[u % C][p] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[u][ti].x, x[u][tj].y, im[u % C][p], 0, 0, 0);
                 }
         }
+        __builtin_amdgcn_sched_barrier(0);   // the other buffer's loads stay where they are written: behind these MFMAs
     };
-    // two buffers, no copies between them: while one feeds the matrix cores the other one's loads are in flight, and the
-    // wait in front of the MFMAs is for the OLDER buffer only (a register copy at the loop end made the compiler wait for
-    // every outstanding load in the middle of the MFMAs: one buffer in flight per wave, 4.3 TB/s)
-    // Every fetch is unconditional (past the end a wave re-reads its first chunk and drops it): with loads under a
-    // branch the compiler cannot count how many younger loads are in flight and waits for all of them.
-    amp_t xa[RDM_U][T], xb[RDM_U][T];
+    // A ring of NBUF buffers, no copies between them: while one feeds the matrix cores the loads of the NBUF - 1 others
+    // are in flight, and the wait in front of the MFMAs is for the OLDEST buffer only (a register copy at the loop end
+    // made the compiler wait for every outstanding load in the middle of the MFMAs: one buffer in flight per wave,
+    // 4.3 TB/s).  Every fetch is unconditional (past the end a wave re-reads its first chunk and drops it): with loads
+    // under a branch the compiler cannot count how many younger loads are in flight and waits for all of them.
+    // T = 4 runs one wave per SIMD (160 accumulator registers) and an update is 40 MFMAs = 1 us: three buffers ahead
+    // cover the HBM latency; T = 1 has four waves per SIMD and needs one.
+    constexpr int NBUF = T == 1 ? 2 : T == 2 ? 3 : 4;
+    amp_t x[NBUF][RDM_U][T];
     const uint64_t first = wave * RDM_U;
-    uint64_t q0 = first;
-    fetch(xa, q0);
-    for (;;) {
-        q0 += stride;
-        fetch(xb, q0 < steps ? q0 : first);
-        update(xa);
-        if (q0 >= steps) break;
-        q0 += stride;
-        fetch(xa, q0 < steps ? q0 : first);
-        update(xb);
-        if (q0 >= steps) break;
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) {
+        const uint64_t q = first + b * stride;
+        fetch(x[b], q < steps ? q : first);
+    }
+    for (uint64_t q0 = first; q0 < steps;) {
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) {
+            const uint64_t q = q0 + (NBUF - 1) * stride;
+            fetch(x[(b + NBUF - 1) % NBUF], q < steps ? q : first);
+            update(x[b]);
+            q0 += stride;
+            if (q0 >= steps) break;
+        }
     }
 #pragma unroll
     for (int c = 1; c < C; ++c)
