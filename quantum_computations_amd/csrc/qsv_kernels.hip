@@ -492,78 +492,84 @@ struct Mfma6Args {
     uint32_t pos[8];     // ascending target bits (all >= 4)
 };
 
-template <bool NT, bool REALM>
-__global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dense6_mfma(amp_t *__restrict__ a, const Mfma6Args g,
-                                                           const double *__restrict__ Mcol,  // [plane][col][row]
-                                                           const uint64_t *__restrict__ hoff) {
+template <int K, bool NT, bool REALM>
+__global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, K == 6 ? 2 : 3))) void k_dense_mfma(
+    amp_t *__restrict__ a, const Mfma6Args g, const double *__restrict__ Mcol,  // [plane][col][row]
+    const uint64_t *__restrict__ hoff) {
+    constexpr int D = 1 << K, SL = D / 4 /* k-slices */, RT = D / 16 /* row tiles */;
     extern __shared__ __attribute__((aligned(16))) char smem6[];
     double *mre = reinterpret_cast<double *>(smem6);
-    double *mim = mre + 4096;
-    uint64_t *off = reinterpret_cast<uint64_t *>(mre + (REALM ? 4096 : 8192));
-    for (int i = threadIdx.x; i < (REALM ? 4096 : 8192); i += QSV_BLOCK) mre[i] = Mcol[i];
-    if (threadIdx.x < 64) off[threadIdx.x] = hoff[threadIdx.x];
+    double *mim = mre + D * D;
+    uint64_t *off = reinterpret_cast<uint64_t *>(mre + (REALM ? 1 : 2) * D * D);
+    for (int i = threadIdx.x; i < (REALM ? 1 : 2) * D * D; i += QSV_BLOCK) mre[i] = Mcol[i];
+    if (threadIdx.x < D) off[threadIdx.x] = hoff[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const uint64_t wave = blockIdx.x * (QSV_BLOCK / 64) + (threadIdx.x >> 6);
     const uint64_t waves = static_cast<uint64_t>(gridDim.x) * (QSV_BLOCK / 64);
     const uint64_t tiles = g.W / 16;
     if (wave >= tiles) return;
-    auto fetch = [&](amp_t (&x)[16], uint64_t tile) {
+    auto fetch = [&](amp_t (&x)[SL], uint64_t tile) {
         const uint64_t base = deposit<6>(tile * 16 + li, g);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) x[s] = ld<NT>(a + base + off[4 * s + lk]);
+        for (int s = 0; s < SL; ++s) x[s] = ld<NT>(a + base + off[4 * s + lk]);
     };
-    auto apply = [&](const amp_t (&x)[16], uint64_t tile) {
-        f64x4 cre[4], cim[4];
+    auto apply = [&](const amp_t (&x)[SL], uint64_t tile) {
+        f64x4 cre[RT], cim[RT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) cre[t] = cim[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < RT; ++t) cre[t] = cim[t] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            double are[4], aim[4];
+        for (int s = 0; s < SL; ++s) {
+            double are[RT], aim[RT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                are[t] = mre[(4 * s + lk) * 64 + 16 * t + li];
-                if constexpr (!REALM) aim[t] = mim[(4 * s + lk) * 64 + 16 * t + li];
+            for (int t = 0; t < RT; ++t) {
+                are[t] = mre[(4 * s + lk) * D + 16 * t + li];
+                if constexpr (!REALM) aim[t] = mim[(4 * s + lk) * D + 16 * t + li];
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {  // dependent updates of one accumulator stay 8 instructions apart
+            for (int t = 0; t < RT; ++t) {  // dependent updates of one accumulator stay 2 RT instructions apart
                 cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[t], x[s].x, cre[t], 0, 0, 0);
                 cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[t], x[s].y, cim[t], 0, 0, 0);
             }
             if constexpr (!REALM) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < RT; ++t) {
                     cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aim[t], x[s].y, cre[t], 0, 0, 0);
                     cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[t], x[s].x, cim[t], 0, 0, 0);
                 }
             }
             // keep the matrix reads of slice s + 1 behind the MFMAs of slice s: hoisted to the top (the scheduler's
-            // choice without this fence) the 16 slices' operands need 256 VGPRs and spill
+            // choice without this fence) the slices' operands need up to 256 VGPRs and spill
             __builtin_amdgcn_sched_barrier(0);
         }
         // in place: the wave has read every amplitude of its 16 groups before the first of these stores can issue
         const uint64_t base = deposit<6>(tile * 16 + li, g);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 st<NT>(a + base + off[16 * t + lk + 4 * r], amp_t{cre[t][r], cim[t][r]});
     };
-    // Two input buffers, no copies between them: the next tile's 16 loads are in flight while this tile's 256 (128)
-    // MFMAs run.  Every fetch is unconditional -- past the end a wave re-reads its first tile and drops it -- because the
-    // compiler cannot count loads issued under a branch and would wait for all of them (see k_rdm).
-    amp_t xa[16], xb[16];
-    uint64_t tile = wave;
-    fetch(xa, tile);
-    for (;;) {
-        const uint64_t t1 = tile + waves;
-        fetch(xb, t1 < tiles ? t1 : wave);
-        apply(xa, tile);
-        if (t1 >= tiles) break;
-        tile = t1 + waves;
-        fetch(xa, tile < tiles ? tile : wave);
-        apply(xb, t1);
-        if (tile >= tiles) break;
+    // A ring of input buffers, no copies between them: the next tiles' loads are in flight while this tile's MFMAs run
+    // (K = 6: 256 MFMAs = 7 us per tile, one tile ahead; K = 5: 64 MFMAs = 1.7 us, two ahead).  Every fetch is
+    // unconditional -- past the end a wave re-reads its first tile and drops it -- because the compiler cannot count
+    // loads issued under a branch and would wait for all of them (see k_rdm).
+    constexpr int NBUF = K == 6 ? 2 : 3;
+    amp_t x[NBUF][SL];
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) {
+        const uint64_t t = wave + b * waves;
+        fetch(x[b], t < tiles ? t : wave);
+    }
+    for (uint64_t tile = wave; tile < tiles;) {
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) {
+            const uint64_t t = tile + (NBUF - 1) * waves;
+            fetch(x[(b + NBUF - 1) % NBUF], t < tiles ? t : wave);
+            apply(x[b], tile);
+            tile += waves;
+            if (tile >= tiles) break;
+        }
     }
 }
 
@@ -1781,26 +1787,27 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
 }
 
 
-// k = 6 on the matrix cores (k_dense6_mfma).  bits[j] = bit position of matrix leg j (leg 0 most significant).
-static int launch_dense6(qsv_state *st, const int *bits, const double *m_user) {
-    constexpr int D = 64;
+// k = 5 (complex matrices) and k = 6 on the matrix cores (k_dense_mfma).  bits[j] = bit position of matrix leg j (leg 0
+// most significant).
+static int launch_dense_mfma(qsv_state *st, int k, const int *bits, const double *m_user) {
+    const int D = 1 << k;
     // A wave's 16 lanes li are the 16 lowest free index values and its 4 lanes lk the two lowest target bits, so a
     // wave-instruction covers whole 128-byte lines wherever the targets sit, unless bits 0, 1 AND 2 are all targets
     // (then it covers half lines, and the other half follows in the next instruction of the same wave): 2.9-3.1 ms at
     // every placement.  (Round 2 first moved low targets away with a qubit permutation before and after: 6.2 ms.)
-    const std::vector<int> tb(bits, bits + 6);
+    const std::vector<int> tb(bits, bits + k);
     std::vector<int> sorted(tb);
     std::sort(sorted.begin(), sorted.end());
     // register / matrix index c: bit i <-> sorted[i]
     std::vector<uint64_t> off(D, 0);
     for (int c = 0; c < D; ++c)
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < k; ++i)
             if ((c >> i) & 1) off[c] |= 1ull << sorted[i];
     auto user_index = [&](int c) {
         int u = 0;
-        for (int leg = 0; leg < 6; ++leg)
-            for (int i = 0; i < 6; ++i)
-                if (sorted[i] == tb[leg]) u |= ((c >> i) & 1) << (5 - leg);
+        for (int leg = 0; leg < k; ++leg)
+            for (int i = 0; i < k; ++i)
+                if (sorted[i] == tb[leg]) u |= ((c >> i) & 1) << (k - 1 - leg);
         return u;
     };
     bool real_matrix = true;
@@ -1821,34 +1828,44 @@ static int launch_dense6(qsv_state *st, const int *bits, const double *m_user) {
     QSV_HIP(hipStreamSynchronize(st->stream));  // both sources are pageable host memory that dies at return
     Mfma6Args g;
     std::memset(&g, 0, sizeof(g));
-    g.W = st->amps >> 6;
-    g.nins = 6;
-    for (int i = 0; i < 6; ++i) g.pos[i] = static_cast<uint32_t>(sorted[i]);
+    g.W = st->amps >> k;
+    g.nins = k;
+    for (int i = 0; i < k; ++i) g.pos[i] = static_cast<uint32_t>(sorted[i]);
     const bool nt = st->nontemporal != 0;
-    const size_t lds = sizeof(double) * (real_matrix ? 4096 : 8192) + sizeof(uint64_t) * 64;
+    const size_t lds = sizeof(double) * (real_matrix ? 1 : 2) * D * D + sizeof(uint64_t) * D;
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st->device);  // 256 if the query fails
-    const uint64_t wave_tiles = (g.W + 15) / 16;
-    const unsigned grid = static_cast<unsigned>(std::min<uint64_t>((wave_tiles + 3) / 4, 2ull * cus));
-    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense6_mfma<%s, %s>", nt ? "true" : "false",
+    const uint64_t wave_tiles = g.W / 16;
+    const unsigned grid = static_cast<unsigned>(std::min<uint64_t>((wave_tiles + 3) / 4, (k == 6 ? 2ull : 3ull) * cus));
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_mfma<%d, %s, %s>", k, nt ? "true" : "false",
              real_matrix ? "true" : "false");
-#define QSV_LAUNCH6(N, R)                                                                                          \
+#define QSV_LAUNCH_MFMA(KK, N, R)                                                                                  \
     do {                                                                                                           \
-        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense6_mfma<N, R>),                           \
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_mfma<KK, N, R>),                        \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
-        hipLaunchKernelGGL((k_dense6_mfma<N, R>), dim3(grid), dim3(QSV_BLOCK), lds, st->stream, st->data, g,       \
+        hipLaunchKernelGGL((k_dense_mfma<KK, N, R>), dim3(grid), dim3(QSV_BLOCK), lds, st->stream, st->data, g,    \
                            st->dev_matrix, dev_off);                                                               \
     } while (0)
-    if (nt) { if (real_matrix) QSV_LAUNCH6(true, true); else QSV_LAUNCH6(true, false); }
-    else { if (real_matrix) QSV_LAUNCH6(false, true); else QSV_LAUNCH6(false, false); }
-#undef QSV_LAUNCH6
+    if (k == 6) {
+        if (nt) { if (real_matrix) QSV_LAUNCH_MFMA(6, true, true); else QSV_LAUNCH_MFMA(6, true, false); }
+        else { if (real_matrix) QSV_LAUNCH_MFMA(6, false, true); else QSV_LAUNCH_MFMA(6, false, false); }
+    } else {
+        if (nt) { if (real_matrix) QSV_LAUNCH_MFMA(5, true, true); else QSV_LAUNCH_MFMA(5, true, false); }
+        else { if (real_matrix) QSV_LAUNCH_MFMA(5, false, true); else QSV_LAUNCH_MFMA(5, false, false); }
+    }
+#undef QSV_LAUNCH_MFMA
     return check_launch();
 }
 
 int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user) {
     if (k < 1 || k > QSV_MAX_K) return qsv_fail(QSV_EINVAL, "generic gate: k must be in 1..6");
-    // 2^(n-6) groups must fill whole waves of 16 and the permutation needs four free bits above the lane bits
-    if (k == 6 && st->n >= 16 && st->kq_variant == 0) return launch_dense6(st, bits, m_user);
+    // matrix-core form: the 2^(n-k) groups must fill whole waves of 16
+    const bool mfma_ok = st->n >= k && (st->amps >> k) >= 16;
+    if (k == 6 && mfma_ok && st->kq_variant == 0) return launch_dense_mfma(st, 6, bits, m_user);
+    if (k == 5 && mfma_ok && st->kq_variant == 5) return launch_dense_mfma(st, 5, bits, m_user);
+    // (k = 5 on the matrix cores is a measurement variant only: on the benchmark circuit's fused blocks it wins where its
+    // wave-instructions cover >= 512 contiguous bytes and the other targets are low (1.50 against 1.66 ms), loses with
+    // targets above bit 18 (1.8-1.9 against 1.65), and over the whole circuit ties with the vector kernels: 28.3 ms both)
     if (k >= 3 && k <= 6 && st->n >= k) {
         const int rc_big = launch_dense_big(st, k, bits, m_user);
         if (rc_big != QSV_UNHANDLED_KQ) return rc_big;

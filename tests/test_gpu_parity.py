@@ -248,7 +248,7 @@ def test_generic_kq(n, k):
 
 
 def test_six_qubit_gates_on_the_matrix_cores():
-    """k = 6 on registers of 16+ qubits runs on the f64 matrix cores (k_dense6_mfma): complex and real 64 x 64
+    """k = 6 on registers of 16+ qubits runs on the f64 matrix cores (k_dense_mfma<6>): complex and real 64 x 64
     matrices, targets all high, mixed, with one to all six of them on the lowest index bits (lanes then run over the
     lowest free bits), legs in any order; against the oracle."""
     n = 16
@@ -265,19 +265,19 @@ def test_six_qubit_gates_on_the_matrix_cores():
         qs = [n - 1 - b for b in bits]
         u = W.haar_unitary(64, rng) if i % 2 == 0 else np.linalg.qr(rng.standard_normal((64, 64)))[0]
         dev.apply_matrix(u, qs)
-        assert dev.last_kernel().startswith("k_dense6_mfma<"), dev.last_kernel()
+        assert dev.last_kernel().startswith("k_dense_mfma<6, "), dev.last_kernel()
         want = O.apply_gate(want, u, qs)
         assert maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL, bits
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("k", [3, 4, 5])
 def test_register_blocked_kq_every_low_target_set(k, variant):
     """k = 3..5 dense gates with EVERY set of target bits below 6 (all subsets of the six lane bits, up to k of them),
     the other legs on random high bits, legs in any order, complex and real matrices.  ``variant`` 3 is the
     line-granular kernel (k_dense_lds: address arithmetic for lane bits 3..5, LDS for bits 0..2), 1 the wave-shuffle
     form (k_dense_big<K, KL>), 2 the no-exchange form, 4 the workgroup tile staged through LDS (k_dense_tile: k = 4, 5 with every target on bit 3
-    or higher), 0 the shipped per-case choice between them: all must agree with the oracle."""
+    or higher), 5 the matrix-core kernel (k_dense_mfma<5>; k = 3, 4 as 0), 0 the shipped per-case choice between them: all must agree with the oracle."""
     import itertools
 
     from quantum_computations_amd import _lib
@@ -311,6 +311,8 @@ def test_register_blocked_kq_every_low_target_set(k, variant):
         assert {name.split(", ")[1] for name in kernels} == {str(j) for j in range(k + 1)}, kernels
     elif variant == 4:
         assert any(name.startswith(f"k_dense_tile<{k}, ") for name in kernels), kernels
+    elif variant == 5:
+        assert all(name.startswith("k_dense_mfma<5, ") for name in kernels) == (k == 5), kernels
     else:
         assert kernels == {f"k_dense_big<{k}, 0, false>"} or kernels == {f"k_dense_big<{k}, 0, true>",
                                                                         f"k_dense_big<{k}, 0, false>"}, kernels

@@ -32,6 +32,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=28)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--k5", action="store_true")
     ap.add_argument("--out", default="gpurun_out/sweep_kq.txt")
     args = ap.parse_args()
     n = args.n
@@ -49,7 +50,7 @@ def main():
     gbytes = 2 * 16 * (1 << n) / 1e9
     emit(f"# n={n} register {16 * (1 << n) / 2**30:.2f} GiB, algorithmic {gbytes:.3f} GB per gate, reps={args.reps}")
     emit("# variant 3 = line-granular (k_dense_lds), 1 = wave shuffles (k_dense_big<K,KL>), 2 = no exchange, 0 = shipped per-case choice")
-    for k in (5, 4, 3):
+    for k in ((5,) if args.k5 else (5, 4, 3)):
         uc = W.haar_unitary(1 << k, rng)
         ur = np.linalg.qr(rng.standard_normal((1 << k, 1 << k)))[0]
         sets = {"high": [8 + 3 * j for j in range(k)], "top": [n - 1 - j for j in range(k)],
@@ -69,12 +70,12 @@ def main():
             sets["5 low (b0..b4) = last d=32 mode"] = [0, 1, 2, 3, 4]
             sets["5 low (b1..b5)"] = [1, 2, 3, 4, 5]
             sets["mode 4 of 6 (b5..b9)"] = [5, 6, 7, 8, 9]
-        emit(f"\n## k = {k}: ms / GB/s per target-bit set; columns: variant 3 complex | variant 3 real | variant 1 | variant 2 | variant 4 (tile) complex | variant 4 real | shipped choice complex | shipped choice real")
+        emit(f"\n## k = {k}: ms / GB/s per target-bit set; columns: variant 3 complex | variant 3 real | variant 1 | variant 2 | variant 4 (tile) complex | variant 4 real | variant 5 (MFMA, k = 5) complex | shipped choice complex | shipped choice real")
         for label, bits in sets.items():
             qs = [n - 1 - b for b in bits]
             cells = []
             name0 = ""
-            for variant, u in ((3, uc), (3, ur), (1, uc), (2, uc), (4, uc), (4, ur), (0, uc), (0, ur)):
+            for variant, u in ((3, uc), (3, ur), (1, uc), (2, uc), (4, uc), (4, ur), (5, uc), (0, uc), (0, ur)):
                 dev.set_option(_lib.OPT_KQ_VARIANT, variant)
                 ms = timed(dev, lambda: dev.apply_matrix(u, qs), args.reps)
                 cells.append(f"{ms:7.3f} ms {gbytes / (ms * 1e-3):6.0f}")
