@@ -1637,7 +1637,9 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     bool real_matrix = true;
     for (int i = 0; i < D * D && real_matrix; ++i) real_matrix = m_user[2 * i + 1] == 0.0;
     // shipped choice: k = 3, 4, and k = 5 with a real matrix (a complex 32 x 32 product per column keeps the FP64 pipe busy
-    // for 0.9 of the 1.4 ms the memory traffic takes; the tile form's extra LDS round trip then costs more than it hides)
+    // for 0.9 of the 1.4 ms the memory traffic takes; the tile form's extra LDS round trip then costs more than it hides.
+    // A persistent form with two LDS tiles and the next tile's loads in flight during the arithmetic was measured too:
+    // 1.86 ms -- two workgroups per CU leave the FMA chains exposed to the scalar-load and LDS latencies)
     const bool use_tile = tile_ok && (st->kq_variant == 4 || (st->kq_variant == 0 && (k <= 4 || real_matrix)));
     const bool transposed = KL > 0 && static_cast<int>(standin.size()) == KL && st->kq_variant != 2 && !use_tile;
     if (!transposed) {  // all targets high, or a register too small to transpose: lanes = lowest free bits
