@@ -295,3 +295,32 @@ def test_block_operator_on_the_last_two_modes(n_modes, d):
     m[np.ix_(idx, idx)] = q
     want = CO.apply_two_axes(want, m, a, b)
     assert maxdiff(st.to_numpy(), want) < 1e-12
+
+
+@pytest.mark.parametrize("real", [True, False])
+def test_block_operator_with_unequally_spaced_elements_on_an_interior_pair(real):
+    """``qsv_apply_mode2_blocks`` away from the last modes (R >= 8: 256-thread form) with index sets that are not a
+    constant step apart (offset-table addressing instead of first + c * step), sizes 1..7 (rows padded to 4 and 8),
+    real and complex block matrices, both leg orders."""
+    d, n_modes = 8, 3
+    rng = np.random.default_rng(88 + real)
+    psi = rng.standard_normal((d,) * n_modes) + 1j * rng.standard_normal((d,) * n_modes)
+    st = QuditState.from_numpy(psi)
+    want = psi
+    cells = rng.permutation(d * d)
+    blocks, at = [], 0
+    for size in (7, 5, 4, 3, 2, 1, 6):
+        idx = [int(c) for c in cells[at:at + size]]
+        at += size
+        m = rng.standard_normal((size, size))
+        if not real:
+            m = m + 1j * rng.standard_normal((size, size))
+        blocks.append((idx, np.linalg.qr(m)[0]))
+    for legs in [(0, 1), (1, 0)]:
+        st.apply_two_mode_blocks(blocks, *legs)
+        assert st.last_kernel() == f"k_mode2_blocks<256, {'true' if real else 'false'}, false>", st.last_kernel()
+        m = np.identity(d * d, dtype=complex)
+        for idx, block in blocks:
+            m[np.ix_(idx, idx)] = block
+        want = CO.apply_two_axes(want, m, *legs)
+        assert maxdiff(st.to_numpy(), want) < 1e-12, legs

@@ -617,6 +617,48 @@ def test_full_size_28q_round_trip_and_known_answers():
     assert abs(out_state.probabilities([(1 << (n - 1)) - 1])[0] - 1.0) < 1e-12
 
 
+def test_full_size_28q_multi_qubit_kernels_round_trip_and_spot_check():
+    """The k = 3..6 kernels at the benchmark's register size (k_dense_tile, k_dense_lds, k_dense_big, k_dense_mfma<6>;
+    complex and real matrices; targets high, low and mixed): unitarity, U then U^dagger restores the state, and after
+    the forward pass a sample of amplitudes agrees with the oracle formula out[r] = sum_c U[r, c] in[c] evaluated from
+    the input amplitudes of the sampled groups alone (size-independent: 2^k inputs per sampled output)."""
+    n = 28
+    rng = np.random.default_rng(2828)
+    dev = DeviceState.random(n, seed=29)
+    ref = dev.copy()
+    cases = [[8, 11, 14], [0, 1, 2], [3, 4, 5, 7], [0, 7, 11, 15], [20, 21, 22, 23], [8, 11, 14, 17, 20],
+             [0, 1, 2, 3, 4], [3, 9, 15, 24, 26], [5, 6, 7, 8, 9], [0, 3, 7, 12, 19, 26], [8, 11, 14, 17, 20, 23]]
+    applied, kernels = [], set()
+    for i, bits in enumerate(cases):
+        k = len(bits)
+        qs = [n - 1 - b for b in bits]
+        u = W.haar_unitary(1 << k, rng) if i % 2 == 0 else np.linalg.qr(rng.standard_normal((1 << k, 1 << k)))[0]
+        # spot check: 6 random groups; input amplitudes before, outputs after
+        others = [b for b in range(n) if b not in bits]
+        bases = []
+        for _ in range(6):
+            v = int(rng.integers(0, 1 << (n - k)))
+            bases.append(sum(((v >> j) & 1) << b for j, b in enumerate(others)))
+        def members(base):
+            # index of the basis state with the target qubits spelling c (qs[0] most significant, as in O.apply_gate)
+            return [base | sum(((c >> (k - 1 - leg)) & 1) << bits[leg] for leg in range(k)) for c in range(1 << k)]
+        idx = [j for base in bases for j in members(base)]
+        before = np.array([dev.download(j, 1)[0] for j in idx])
+        dev.apply_matrix(u, qs)
+        kernels.add(dev.last_kernel().split("<")[0])
+        after = np.array([dev.download(j, 1)[0] for j in idx])
+        for g in range(len(bases)):
+            sl = slice(g << k, (g + 1) << k)
+            assert maxdiff(after[sl], u @ before[sl]) < 1e-15, (bits, dev.last_kernel())
+        applied.append((u, qs))
+    assert abs(dev.norm2() - 1.0) < 1e-10
+    assert abs(dev.inner(ref)) < 0.99
+    assert {"k_dense_tile", "k_dense_lds", "k_dense_big", "k_dense_mfma"} <= kernels, kernels
+    for u, qs in reversed(applied):
+        dev.apply_matrix(np.conjugate(u).T, qs)
+    assert abs(dev.inner(ref) - 1.0) < 1e-10
+
+
 def test_33_qubit_register_uses_64_bit_indices():
     """128 GiB register: amplitude indices beyond 2^32 (the 34-qubit config shards to 2^31 amplitudes per GPU; this
     exercises the same index arithmetic on one device).  Known answers only -- no host copy of the state exists."""
