@@ -515,6 +515,10 @@ class ShardedState:
         if k == 2 and np.array_equal(m, _SWAP):
             return self.apply_swap(*qubits)           # a relabelling of the qubit map: no data moves
         self._advance_plan(qubits)
+        bits = [self._bit(q) for q in qubits]
+        if all(b < self.n_local for b in bits):       # every leg inside the shard: nothing to decide
+            self.local.apply_matrix(m, [self._local_qubit(b) for b in bits])
+            return self
         conserved = [_leg_is_block_diagonal(m, k, j) for j in range(k)]
         mixing = [q for q, c in zip(qubits, conserved) if not c]
         if len(mixing) > self.n_local:
