@@ -73,7 +73,7 @@ __device__ __forceinline__ uint64_t insert_zero(uint64_t w, int p) {
 // followed by s_waitcnt vmcnt(0) in front of every amplitude load -- which also drains every amplitude load already in
 // flight (k_rdm ran at 1.3-2.3 TB/s that way; rocprof: 60-70 % of the wave cycles parked).  A dword array is indexed
 // with s_load_dword.
-template <int STATIC = 4, class Args>
+template <class Args>
 __device__ __forceinline__ uint64_t deposit(uint64_t w, const Args &g) {
     for (int j = 0; j < g.nins; ++j) w = insert_zero(w, static_cast<int>(g.pos[j]));
     return w | g.or_mask;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_dense_big(amp_t *__restrict__ a, 
                               : blockIdx.x;
     const uint64_t w = g.w0 + tile * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x;
     if (w >= g.W) return;  // W and w0 are multiples of 64 whenever KL > 0: whole waves leave together
-    const uint64_t base = deposit<10>(w, g);
+    const uint64_t base = deposit(w, g);
     amp_t x[D];
 #pragma unroll
     for (int c = 0; c < D; ++c) x[c] = ld<NT>(a + base + hoff[c]);
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(BLOCK) void k_dense_lds(amp_t *__restrict__ a, cons
     if (w >= g.W) return;  // W and w0 are multiples of 64: whole waves leave together
     const uint32_t lane = threadIdx.x & 63;
     // row of this lane: its A bits move from the column to the stand-in bits
-    uint64_t base = deposit<10>(w, g) & ~static_cast<uint64_t>(g.amask);
+    uint64_t base = deposit(w, g) & ~static_cast<uint64_t>(g.amask);
     for (int j = 0; j < g.na; ++j) base |= static_cast<uint64_t>((lane >> g.abit[j]) & 1u) << g.aE[j];
     amp_t x[D];
 #pragma unroll
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, K 
     const uint64_t tiles = g.W / 16;
     if (wave >= tiles) return;
     auto fetch = [&](amp_t (&x)[SL], uint64_t tile) {
-        const uint64_t base = deposit<6>(tile * 16 + li, g);
+        const uint64_t base = deposit(tile * 16 + li, g);
 #pragma unroll
         for (int s = 0; s < SL; ++s) x[s] = ld<NT>(a + base + off[4 * s + lk]);
     };
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, K 
             __builtin_amdgcn_sched_barrier(0);
         }
         // in place: the wave has read every amplitude of its 16 groups before the first of these stores can issue
-        const uint64_t base = deposit<6>(tile * 16 + li, g);
+        const uint64_t base = deposit(tile * 16 + li, g);
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_rdm(const amp_t *__restrict__ a, 
     auto fetch = [&](amp_t (&x)[RDM_U][T], uint64_t q0) {
 #pragma unroll
         for (int u = 0; u < RDM_U; ++u) {
-            const uint64_t base = deposit<6>(((q0 + u) * 4 + kk) * S + sub, g);
+            const uint64_t base = deposit(((q0 + u) * 4 + kk) * S + sub, g);
 #pragma unroll
             for (int t = 0; t < T; ++t) x[u][t] = __builtin_nontemporal_load(a + base + row_off[t]);
         }
