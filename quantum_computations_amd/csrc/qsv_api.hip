@@ -215,6 +215,10 @@ int qsv_destroy(qsv_state *st) {
     if (st->partials) (void)hipFree(st->partials);
     if (st->partials_host) (void)hipHostFree(st->partials_host);
     if (st->dev_matrix) (void)hipFree(st->dev_matrix);
+    if (st->stage_dev) (void)hipFree(st->stage_dev);
+    if (st->stage_host) (void)hipHostFree(st->stage_host);
+    for (hipEvent_t ev : st->stage_done)
+        if (ev) (void)hipEventDestroy(ev);
     if (st->ev_start) (void)hipEventDestroy(st->ev_start);
     if (st->ev_stop) (void)hipEventDestroy(st->ev_stop);
     for (hipEvent_t ev : st->marks)

@@ -68,6 +68,12 @@ struct qsv_state {
     double *partials_host = nullptr;  // pinned host mirror
     double *dev_matrix = nullptr;     // device: matrix / table of the generic kernels
     size_t dev_matrix_bytes = 0;
+    // staging ring for gate matrices and tables (qsvk_stage): pinned host slots mirrored by device slots
+    char *stage_host = nullptr;       // QSV_STAGE_SLOTS x QSV_STAGE_BYTES, pinned
+    char *stage_dev = nullptr;        // the same on the device
+    hipEvent_t stage_done[8] = {};    // kernel that read slot i has finished
+    bool stage_busy[8] = {};
+    unsigned stage_next = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     std::vector<hipEvent_t> marks;    // lazily created events of qsv_event_record
     // options
@@ -87,6 +93,17 @@ struct qsv_state {
 };
 
 constexpr int QSV_REDUCE_BLOCKS = 1024;
+constexpr int QSV_STAGE_SLOTS = 8;
+constexpr size_t QSV_STAGE_BYTES = 512u << 10;
+
+// A gate's matrix / tables on their way to the device without a host-side wait (see qsvk_stage in qsv_kernels.hip).
+struct StageRef {
+    char *dev = nullptr;   // device address of part A; part B follows at pad16(bytes of A)
+    int slot = -1;         // ring slot, or -1: the data went through st->dev_matrix with a synchronous copy
+};
+int qsvk_stage(qsv_state *st, const void *a, size_t bytes_a, const void *b, size_t bytes_b, StageRef *out);
+int qsvk_stage_done(qsv_state *st, const StageRef &ref);   // call right after the launch that reads the slot
+inline size_t qsv_pad16(size_t x) { return (x + 15) / 16 * 16; }
 
 // error plumbing (qsv_api.hip)
 int qsv_fail(int code, const std::string &msg);

@@ -1445,6 +1445,70 @@ int qsvk_ensure_matrix(qsv_state *st, size_t bytes) {
     return QSV_OK;
 }
 
+// Gate matrices and index tables come from host memory that dies when the call returns.  Copying them to the device
+// with hipMemcpyAsync + hipStreamSynchronize makes every such gate wait for the previous kernel before its own launch
+// can even be queued: 72 us of idle GPU between the fused blocks of a circuit (4 % of the pass at n = 28, two thirds of
+// it at n = 22).  Instead the data is copied into the next slot of a pinned ring by the CPU, a transfer to the slot's
+// device mirror is queued on the register's stream in front of the kernel, and an event recorded behind the
+// kernel says when the slot may be overwritten -- the host only ever waits when it is a whole ring ahead of the GPU.
+// Payloads larger than a slot take the synchronous road through st->dev_matrix.
+// The transfer itself is a small kernel that reads the pinned slot over PCIe (pinned host memory is mapped into the
+// device's address space): a copy-engine transfer queued between two kernels starts ~45 us after the first kernel ends
+// (the dependency crosses from the compute queue to the SDMA queue), a kernel behind a kernel on the same queue ~5 us.
+__global__ __launch_bounds__(QSV_BLOCK) void k_stage_copy(uint4 *__restrict__ dst, const uint4 *__restrict__ src, uint32_t n16) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+int qsvk_stage(qsv_state *st, const void *a, size_t bytes_a, const void *b, size_t bytes_b, StageRef *out) {
+    const size_t off_b = qsv_pad16(bytes_a), total = off_b + bytes_b;
+    if (total > QSV_STAGE_BYTES) {
+        const int rc = qsvk_ensure_matrix(st, total);
+        if (rc) return rc;
+        char *dev = reinterpret_cast<char *>(st->dev_matrix);
+        if (bytes_a) QSV_HIP(hipMemcpyAsync(dev, a, bytes_a, hipMemcpyHostToDevice, st->stream));
+        if (bytes_b) QSV_HIP(hipMemcpyAsync(dev + off_b, b, bytes_b, hipMemcpyHostToDevice, st->stream));
+        QSV_HIP(hipStreamSynchronize(st->stream));  // the sources are pageable host memory that dies at return
+        out->dev = dev;
+        out->slot = -1;
+        return QSV_OK;
+    }
+    if (!st->stage_dev) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&st->stage_host), QSV_STAGE_SLOTS * QSV_STAGE_BYTES, 0) != hipSuccess) {
+            st->stage_host = nullptr;
+            return qsv_fail(QSV_ENOMEM, "pinned allocation of the gate-matrix staging ring failed");
+        }
+        if (hipMalloc(reinterpret_cast<void **>(&st->stage_dev), QSV_STAGE_SLOTS * QSV_STAGE_BYTES) != hipSuccess) {
+            (void)hipHostFree(st->stage_host);
+            st->stage_host = nullptr;
+            st->stage_dev = nullptr;
+            return qsv_fail(QSV_ENOMEM, "device allocation of the gate-matrix staging ring failed");
+        }
+        for (auto &ev : st->stage_done) QSV_HIP(hipEventCreate(&ev));
+    }
+    const int slot = static_cast<int>(st->stage_next++ % QSV_STAGE_SLOTS);
+    if (st->stage_busy[slot]) {
+        QSV_HIP(hipEventSynchronize(st->stage_done[slot]));
+        st->stage_busy[slot] = false;
+    }
+    char *host = st->stage_host + slot * QSV_STAGE_BYTES, *dev = st->stage_dev + slot * QSV_STAGE_BYTES;
+    if (bytes_a) std::memcpy(host, a, bytes_a);
+    if (bytes_b) std::memcpy(host + off_b, b, bytes_b);
+    const uint32_t n16 = static_cast<uint32_t>((total + 15) / 16);
+    hipLaunchKernelGGL(k_stage_copy, dim3((n16 + QSV_BLOCK - 1) / QSV_BLOCK < 16 ? (n16 + QSV_BLOCK - 1) / QSV_BLOCK : 16), dim3(QSV_BLOCK), 0,
+                       st->stream, reinterpret_cast<uint4 *>(dev), reinterpret_cast<const uint4 *>(host), n16);
+    QSV_HIP(hipGetLastError());
+    out->dev = dev;
+    out->slot = slot;
+    return QSV_OK;
+}
+
+int qsvk_stage_done(qsv_state *st, const StageRef &ref) {
+    if (ref.slot < 0) return QSV_OK;
+    QSV_HIP(hipEventRecord(st->stage_done[ref.slot], st->stream));
+    st->stage_busy[ref.slot] = true;
+    return QSV_OK;
+}
+
 // Out-of-place operations (measure, insert, permute, the mode contractions) write into the state's spare
 // buffer and then swap it in (qsvk_adopt).  The spare is kept between calls: a circuit that alternates such
 // operations ping-pongs between two allocations instead of paying hipMalloc/hipFree of the register per gate
@@ -1481,10 +1545,10 @@ int qsvk_adopt(qsv_state *st, uint64_t new_amps) {
 
 // k = 3..5 on any register with at least k qubits.
 template <int K, int KL>
-static void launch_big_kernel(qsv_state *st, bool nt, dim3 gd, const BigArgs &g, const uint64_t *dev_off) {
+static void launch_big_kernel(qsv_state *st, bool nt, dim3 gd, const BigArgs &g, const double *dev_m, const uint64_t *dev_off) {
     const dim3 bd(QSV_BLOCK);
-    if (nt) hipLaunchKernelGGL((k_dense_big<K, KL, true>), gd, bd, 0, st->stream, st->data, g, st->dev_matrix, dev_off);
-    else hipLaunchKernelGGL((k_dense_big<K, KL, false>), gd, bd, 0, st->stream, st->data, g, st->dev_matrix, dev_off);
+    if (nt) hipLaunchKernelGGL((k_dense_big<K, KL, true>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
+    else hipLaunchKernelGGL((k_dense_big<K, KL, false>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
 }
 
 // ---- k-qubit dense gate, targets on bits >= 3, staged through LDS: "tile" form -------------------------------------
@@ -1546,8 +1610,8 @@ __global__ __launch_bounds__((1 << K) / ROWS * 64) void k_dense_tile(amp_t *__re
 }
 
 template <int K, int ROWS>
-static int launch_tile_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const BigArgs &g, const uint64_t *dev_off) {
-    const double *m = st->dev_matrix;
+static int launch_tile_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const BigArgs &g, const double *m,
+                              const uint64_t *dev_off) {
     const dim3 bd((1 << K) / ROWS * 64);
     if (nt) {
         if (realm) hipLaunchKernelGGL((k_dense_tile<K, ROWS, true, true>), gd, bd, 0, st->stream, st->data, g, m, dev_off);
@@ -1579,17 +1643,17 @@ static uint32_t tile_regions(int k, const std::vector<int> &sorted_bits) {
 }
 
 template <int K>
-static int dispatch_big(qsv_state *st, int KL, bool nt, dim3 gd, const BigArgs &g, const uint64_t *dev_off) {
+static int dispatch_big(qsv_state *st, int KL, bool nt, dim3 gd, const BigArgs &g, const double *dev_m, const uint64_t *dev_off) {
     switch (KL) {
-        case 0: launch_big_kernel<K, 0>(st, nt, gd, g, dev_off); break;
-        case 1: launch_big_kernel<K, 1>(st, nt, gd, g, dev_off); break;
-        case 2: launch_big_kernel<K, 2>(st, nt, gd, g, dev_off); break;
-        case 3: launch_big_kernel<K, 3>(st, nt, gd, g, dev_off); break;
+        case 0: launch_big_kernel<K, 0>(st, nt, gd, g, dev_m, dev_off); break;
+        case 1: launch_big_kernel<K, 1>(st, nt, gd, g, dev_m, dev_off); break;
+        case 2: launch_big_kernel<K, 2>(st, nt, gd, g, dev_m, dev_off); break;
+        case 3: launch_big_kernel<K, 3>(st, nt, gd, g, dev_m, dev_off); break;
         case 4:
-            if constexpr (K >= 4) launch_big_kernel<K, 4>(st, nt, gd, g, dev_off);
+            if constexpr (K >= 4) launch_big_kernel<K, 4>(st, nt, gd, g, dev_m, dev_off);
             break;
         default:
-            if constexpr (K >= 5) launch_big_kernel<K, 5>(st, nt, gd, g, dev_off);
+            if constexpr (K >= 5) launch_big_kernel<K, 5>(st, nt, gd, g, dev_m, dev_off);
             break;
     }
     return check_launch();
@@ -1598,24 +1662,26 @@ static int dispatch_big(qsv_state *st, int KL, bool nt, dim3 gd, const BigArgs &
 
 
 template <int K, int KB, int BLOCK>
-static void launch_lds_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const LdsArgs &g, const uint64_t *dev_off) {
+static void launch_lds_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const LdsArgs &g, const double *dev_m,
+                              const uint64_t *dev_off) {
     const dim3 bd(BLOCK);
     if (nt) {
-        if (realm) hipLaunchKernelGGL((k_dense_lds<K, KB, true, true, BLOCK>), gd, bd, 0, st->stream, st->data, g, st->dev_matrix, dev_off);
-        else hipLaunchKernelGGL((k_dense_lds<K, KB, true, false, BLOCK>), gd, bd, 0, st->stream, st->data, g, st->dev_matrix, dev_off);
+        if (realm) hipLaunchKernelGGL((k_dense_lds<K, KB, true, true, BLOCK>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
+        else hipLaunchKernelGGL((k_dense_lds<K, KB, true, false, BLOCK>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
     } else {
-        if (realm) hipLaunchKernelGGL((k_dense_lds<K, KB, false, true, BLOCK>), gd, bd, 0, st->stream, st->data, g, st->dev_matrix, dev_off);
-        else hipLaunchKernelGGL((k_dense_lds<K, KB, false, false, BLOCK>), gd, bd, 0, st->stream, st->data, g, st->dev_matrix, dev_off);
+        if (realm) hipLaunchKernelGGL((k_dense_lds<K, KB, false, true, BLOCK>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
+        else hipLaunchKernelGGL((k_dense_lds<K, KB, false, false, BLOCK>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
     }
 }
 
 template <int K, int BLOCK>
-static int dispatch_lds(qsv_state *st, int KB, bool nt, bool realm, dim3 gd, const LdsArgs &g, const uint64_t *dev_off) {
+static int dispatch_lds(qsv_state *st, int KB, bool nt, bool realm, dim3 gd, const LdsArgs &g, const double *dev_m,
+                        const uint64_t *dev_off) {
     switch (KB) {
-        case 0: launch_lds_kernel<K, 0, BLOCK>(st, nt, realm, gd, g, dev_off); break;
-        case 1: launch_lds_kernel<K, 1, BLOCK>(st, nt, realm, gd, g, dev_off); break;
-        case 2: launch_lds_kernel<K, 2, BLOCK>(st, nt, realm, gd, g, dev_off); break;
-        default: launch_lds_kernel<K, 3, BLOCK>(st, nt, realm, gd, g, dev_off); break;
+        case 0: launch_lds_kernel<K, 0, BLOCK>(st, nt, realm, gd, g, dev_m, dev_off); break;
+        case 1: launch_lds_kernel<K, 1, BLOCK>(st, nt, realm, gd, g, dev_m, dev_off); break;
+        case 2: launch_lds_kernel<K, 2, BLOCK>(st, nt, realm, gd, g, dev_m, dev_off); break;
+        default: launch_lds_kernel<K, 3, BLOCK>(st, nt, realm, gd, g, dev_m, dev_off); break;
     }
     return check_launch();
 }
@@ -1691,27 +1757,27 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
                 m[2 * (r * D + c) + 1] = m_user[2 * (ur * D + uc) + 1];
             }
         }
-    const size_t mbytes = sizeof(double) * 2ull * D * D, obytes = sizeof(uint64_t) * D;
-    int rc = qsvk_ensure_matrix(st, mbytes + obytes);
-    if (rc) return rc;
-    uint64_t *dev_off = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(st->dev_matrix) + mbytes);
-    QSV_HIP(hipMemcpyAsync(st->dev_matrix, m.data(), sizeof(double) * m.size(), hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipMemcpyAsync(dev_off, off.data(), obytes, hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipStreamSynchronize(st->stream));  // both sources are pageable host memory that dies at return
     std::vector<int> ins(high);
     ins.insert(ins.end(), standin.begin(), standin.end());
     std::sort(ins.begin(), ins.end());
     const uint64_t W = st->amps >> k;
-    if (use_tile) {
-        // matrix slice of wave q, input c: ROWS consecutive entries  [q][c][i] = m[q ROWS + i][c]
+    if (use_tile) {  // matrix slice of wave q, input c: ROWS consecutive entries  [q][c][i] = m[q ROWS + i][c]
         const int rows = k == 5 ? 8 : k == 4 ? 4 : 2, per = realm ? 1 : 2;
         std::vector<double> mt(m.size());
         for (int r = 0; r < D; ++r)
             for (int c = 0; c < D; ++c)
                 for (int e = 0; e < per; ++e)
                     mt[per * ((static_cast<size_t>(r / rows) * D + c) * rows + r % rows) + e] = m[per * (r * D + c) + e];
-        QSV_HIP(hipMemcpyAsync(st->dev_matrix, mt.data(), sizeof(double) * mt.size(), hipMemcpyHostToDevice, st->stream));
-        QSV_HIP(hipStreamSynchronize(st->stream));
+        m.swap(mt);
+    }
+    // matrix and offsets ride the staging ring to the device: queued on the stream in front of the kernel, no host wait
+    StageRef staged;
+    int rc = qsvk_stage(st, m.data(), sizeof(double) * m.size(), off.data(), sizeof(uint64_t) * D, &staged);
+    if (rc) return rc;
+    const double *dev_m = reinterpret_cast<const double *>(staged.dev);
+    const uint64_t *dev_off = reinterpret_cast<const uint64_t *>(staged.dev + qsv_pad16(sizeof(double) * m.size()));
+    if (use_tile) {
+        const int rows = k == 5 ? 8 : k == 4 ? 4 : 2;
         BigArgs g;
         std::memset(&g, 0, sizeof(g));
         g.W = W;
@@ -1724,12 +1790,12 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
         const uint64_t per_launch = 0x00ffffffull * 64;  // columns per dispatch
         for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
             const dim3 gd(static_cast<unsigned>(std::min(per_launch, g.W - g.w0) / 64));
-            const int rc2 = k == 5 ? launch_tile_kernel<5, 8>(st, nt, realm, gd, g, dev_off)
-                          : k == 4 ? launch_tile_kernel<4, 4>(st, nt, realm, gd, g, dev_off)
-                                   : launch_tile_kernel<3, 2>(st, nt, realm, gd, g, dev_off);
+            const int rc2 = k == 5 ? launch_tile_kernel<5, 8>(st, nt, realm, gd, g, dev_m, dev_off)
+                          : k == 4 ? launch_tile_kernel<4, 4>(st, nt, realm, gd, g, dev_m, dev_off)
+                                   : launch_tile_kernel<3, 2>(st, nt, realm, gd, g, dev_m, dev_off);
             if (rc2) return rc2;
         }
-        return QSV_OK;
+        return qsvk_stage_done(st, staged);
     }
     if (use_lds) {
         LdsArgs g;
@@ -1757,13 +1823,13 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
         const uint64_t per_launch = 0x00ffffffull * QSV_BLOCK;  // an AQL dispatch counts work-items in 32 bits
         for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
             const dim3 gd(grid_for(std::min(per_launch, g.W - g.w0), QSV_BLOCK, 0));
-            const int rc2 = k == 3 ? dispatch_lds<3, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_off)
-                          : k == 4 ? dispatch_lds<4, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_off)
-                          : k == 5 ? dispatch_lds<5, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_off)
-                                   : dispatch_lds<6, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_off);
+            const int rc2 = k == 3 ? dispatch_lds<3, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_m, dev_off)
+                          : k == 4 ? dispatch_lds<4, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_m, dev_off)
+                          : k == 5 ? dispatch_lds<5, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_m, dev_off)
+                                   : dispatch_lds<6, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_m, dev_off);
             if (rc2) return rc2;
         }
-        return QSV_OK;
+        return qsvk_stage_done(st, staged);
     }
     BigArgs g;
     std::memset(&g, 0, sizeof(g));
@@ -1780,12 +1846,12 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     const uint64_t per_launch = 0x00ffffffull * QSV_BLOCK;  // an AQL dispatch counts work-items in 32 bits
     for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
         const dim3 gd(grid_for(std::min(per_launch, g.W - g.w0), QSV_BLOCK, 0));
-        const int rc2 = k == 3 ? dispatch_big<3>(st, KL, nt, gd, g, dev_off)
-                      : k == 4 ? dispatch_big<4>(st, KL, nt, gd, g, dev_off)
-                               : dispatch_big<5>(st, KL, nt, gd, g, dev_off);
+        const int rc2 = k == 3 ? dispatch_big<3>(st, KL, nt, gd, g, dev_m, dev_off)
+                      : k == 4 ? dispatch_big<4>(st, KL, nt, gd, g, dev_m, dev_off)
+                               : dispatch_big<5>(st, KL, nt, gd, g, dev_m, dev_off);
         if (rc2) return rc2;
     }
-    return QSV_OK;
+    return qsvk_stage_done(st, staged);
 }
 
 
@@ -1821,13 +1887,11 @@ static int launch_dense_mfma(qsv_state *st, int k, const int *bits, const double
             m[c * D + r] = m_user[2 * (ur * D + uc)];
             if (!real_matrix) m[D * D + c * D + r] = m_user[2 * (ur * D + uc) + 1];
         }
-    const size_t mbytes = sizeof(double) * 2 * D * D, obytes = sizeof(uint64_t) * D;
-    int rc = qsvk_ensure_matrix(st, mbytes + obytes);
+    StageRef staged;
+    int rc = qsvk_stage(st, m.data(), sizeof(double) * m.size(), off.data(), sizeof(uint64_t) * D, &staged);
     if (rc) return rc;
-    uint64_t *dev_off = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(st->dev_matrix) + mbytes);
-    QSV_HIP(hipMemcpyAsync(st->dev_matrix, m.data(), sizeof(double) * m.size(), hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipMemcpyAsync(dev_off, off.data(), obytes, hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipStreamSynchronize(st->stream));  // both sources are pageable host memory that dies at return
+    const double *dev_m = reinterpret_cast<const double *>(staged.dev);
+    const uint64_t *dev_off = reinterpret_cast<const uint64_t *>(staged.dev + qsv_pad16(sizeof(double) * m.size()));
     Mfma6Args g;
     std::memset(&g, 0, sizeof(g));
     g.W = st->amps >> k;
@@ -1846,7 +1910,7 @@ static int launch_dense_mfma(qsv_state *st, int k, const int *bits, const double
         QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_mfma<KK, N, R>),                        \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
         hipLaunchKernelGGL((k_dense_mfma<KK, N, R>), dim3(grid), dim3(QSV_BLOCK), lds, st->stream, st->data, g,    \
-                           st->dev_matrix, dev_off);                                                               \
+                           dev_m, dev_off);                                                                        \
     } while (0)
     if (k == 6) {
         if (nt) { if (real_matrix) QSV_LAUNCH_MFMA(6, true, true); else QSV_LAUNCH_MFMA(6, true, false); }
@@ -1856,7 +1920,9 @@ static int launch_dense_mfma(qsv_state *st, int k, const int *bits, const double
         else { if (real_matrix) QSV_LAUNCH_MFMA(5, false, true); else QSV_LAUNCH_MFMA(5, false, false); }
     }
 #undef QSV_LAUNCH_MFMA
-    return check_launch();
+    rc = check_launch();
+    if (rc) return rc;
+    return qsvk_stage_done(st, staged);
 }
 
 int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user) {
@@ -1873,10 +1939,10 @@ int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user) {
         if (rc_big != QSV_UNHANDLED_KQ) return rc_big;
     }
     const size_t bytes = sizeof(double) * 2ull << (2 * k);
-    int rc = qsvk_ensure_matrix(st, bytes);
+    StageRef staged;
+    int rc = qsvk_stage(st, m_user, bytes, nullptr, 0, &staged);
     if (rc) return rc;
-    QSV_HIP(hipMemcpyAsync(st->dev_matrix, m_user, bytes, hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipStreamSynchronize(st->stream));  // m_user is the caller's (pageable) memory: see qsvq_mode1
+    const double *dev_m = reinterpret_cast<const double *>(staged.dev);
     GenericArgs g;
     std::memset(&g, 0, sizeof(g));
     g.K = k;
@@ -1890,14 +1956,16 @@ int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user) {
     const int grid = grid_for(g.W, QSV_BLOCK, 4096);
     snprintf(st->last_kernel, sizeof(st->last_kernel), "k_generic<%d>", k);
     switch (k) {
-        case 1: hipLaunchKernelGGL((k_generic<1>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
-        case 2: hipLaunchKernelGGL((k_generic<2>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
-        case 3: hipLaunchKernelGGL((k_generic<3>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
-        case 4: hipLaunchKernelGGL((k_generic<4>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
-        case 5: hipLaunchKernelGGL((k_generic<5>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
-        default: hipLaunchKernelGGL((k_generic<6>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, st->dev_matrix); break;
+        case 1: hipLaunchKernelGGL((k_generic<1>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, dev_m); break;
+        case 2: hipLaunchKernelGGL((k_generic<2>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, dev_m); break;
+        case 3: hipLaunchKernelGGL((k_generic<3>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, dev_m); break;
+        case 4: hipLaunchKernelGGL((k_generic<4>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, dev_m); break;
+        case 5: hipLaunchKernelGGL((k_generic<5>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, dev_m); break;
+        default: hipLaunchKernelGGL((k_generic<6>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, dev_m); break;
     }
-    return check_launch();
+    rc = check_launch();
+    if (rc) return rc;
+    return qsvk_stage_done(st, staged);
 }
 
 // bits[j] = bit position of matrix leg j (leg 0 most significant); k in {1, 2}.
@@ -1996,26 +2064,25 @@ int qsvk_diag(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits
         }
     }
     const size_t tbytes = sizeof(double) * table.size();
-    int rc = qsvk_ensure_matrix(st, tbytes + 64);
-    if (rc) return rc;
     uint8_t pos[8] = {0};
     for (int j = 0; j < K; ++j) pos[j] = static_cast<uint8_t>(legs[j]);
-    QSV_HIP(hipMemcpyAsync(st->dev_matrix, table.data(), tbytes, hipMemcpyHostToDevice, st->stream));
-    uint8_t *dpos = reinterpret_cast<uint8_t *>(st->dev_matrix) + tbytes;
-    QSV_HIP(hipMemcpyAsync(dpos, pos, 8, hipMemcpyHostToDevice, st->stream));
-    // the two pageable-source copies above are staged before return (HIP semantics), so `table` may die
-    QSV_HIP(hipStreamSynchronize(st->stream));
+    StageRef staged;
+    int rc = qsvk_stage(st, table.data(), tbytes, pos, 8, &staged);
+    if (rc) return rc;
+    const double *dtable = reinterpret_cast<const double *>(staged.dev);
+    const uint8_t *dpos = reinterpret_cast<const uint8_t *>(staged.dev + qsv_pad16(tbytes));
     if (st->n >= RO_MIN_QUBITS && st->readout_variant == 0) {
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_diag_table_s");
         hipLaunchKernelGGL(k_diag_table_s, dim3(static_cast<unsigned>(st->amps / (QSV_BLOCK * RO_ITEMS))), dim3(QSV_BLOCK), 0,
-                           st->stream, st->data, st->amps, K, dpos, st->dev_matrix);
-        return check_launch();
+                           st->stream, st->data, st->amps, K, dpos, dtable);
+    } else {
+        const int grid = grid_for(st->amps, QSV_BLOCK, 4096);
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_diag_table");
+        hipLaunchKernelGGL(k_diag_table, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, K, dpos, dtable);
     }
-    const int grid = grid_for(st->amps, QSV_BLOCK, 4096);
-    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_diag_table");
-    hipLaunchKernelGGL(k_diag_table, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, K, dpos,
-                       st->dev_matrix);
-    return check_launch();
+    rc = check_launch();
+    if (rc) return rc;
+    return qsvk_stage_done(st, staged);
 }
 
 int qsvk_phase(qsv_state *st, int nctrl, const int *cbits, double re, double im) {

@@ -757,14 +757,13 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
         x.at = total;
         total += pad16(x.bytes);
     }
-    int rc = qsvk_ensure_matrix(st, total);
-    if (rc) return rc;
-    // one staging image, one copy
+    // one image, one transfer through the staging ring (no host wait: see qsvk_stage)
     std::vector<char> image(total, 0);
     for (auto &x : sec) memcpy(image.data() + x.at, x.src, x.bytes);
-    char *p = reinterpret_cast<char *>(st->dev_matrix);
-    QSV_HIP(hipMemcpyAsync(p, image.data(), total, hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipStreamSynchronize(st->stream));  // the source is pageable host memory that dies at return
+    StageRef staged;
+    int rc = qsvk_stage(st, image.data(), total, nullptr, 0, &staged);
+    if (rc) return rc;
+    char *p = staged.dev;
     const double *t_mats = reinterpret_cast<const double *>(p + sec[0].at);
     const uint64_t *t_off = reinterpret_cast<const uint64_t *>(p + sec[1].at);
     const uint64_t *t_first = reinterpret_cast<const uint64_t *>(p + sec[2].at);
@@ -799,7 +798,9 @@ int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const in
         else QSV_LAUNCH_BLOCKS(64, false, false);
     }
 #undef QSV_LAUNCH_BLOCKS
-    return check_launch();
+    rc = check_launch();
+    if (rc) return rc;
+    return qsvk_stage_done(st, staged);
 }
 
 int qsvq_mode_marginal(qsv_state *st, int mode, double *probs) {
