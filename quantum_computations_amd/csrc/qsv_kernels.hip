@@ -1747,9 +1747,11 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     };
     const bool realm = (use_lds || use_tile) && real_matrix;
     std::vector<double> m(realm ? static_cast<size_t>(D) * D : 2ull * D * D);
+    std::vector<int> ui(D);
+    for (int c = 0; c < D; ++c) ui[c] = user_index(c);
     for (int r = 0; r < D; ++r)
         for (int c = 0; c < D; ++c) {
-            const int ur = user_index(r), uc = user_index(c);
+            const int ur = ui[r], uc = ui[c];
             if (realm) {
                 m[r * D + c] = m_user[2 * (ur * D + uc)];
             } else {
@@ -1881,9 +1883,11 @@ static int launch_dense_mfma(qsv_state *st, int k, const int *bits, const double
     bool real_matrix = true;
     for (int i = 0; i < D * D && real_matrix; ++i) real_matrix = m_user[2 * i + 1] == 0.0;
     std::vector<double> m(real_matrix ? D * D : 2 * D * D);  // [plane][col][row]
+    std::vector<int> ui(D);
+    for (int c = 0; c < D; ++c) ui[c] = user_index(c);
     for (int r = 0; r < D; ++r)
         for (int c = 0; c < D; ++c) {
-            const int ur = user_index(r), uc = user_index(c);
+            const int ur = ui[r], uc = ui[c];
             m[c * D + r] = m_user[2 * (ur * D + uc)];
             if (!real_matrix) m[D * D + c * D + r] = m_user[2 * (ur * D + uc) + 1];
         }

@@ -636,19 +636,20 @@ static int launch_plane(qsv_state *st, uint64_t d, uint64_t L, int nblocks, cons
         }
         trip[t / 64] = std::max(trip[t / 64], el.size);
     }
-    auto pad16 = [](size_t x) { return (x + 15) / 16 * 16; };
-    const size_t b_c = pad16(sizeof(double) * coef.size()), b_i = pad16(sizeof(int32_t) * PLANE_THREADS);
-    int rc = qsvk_ensure_matrix(st, b_c + 3 * b_i);
+    // one image [coef | rd0 | wr | trip] through the staging ring (no host wait: see qsvk_stage)
+    const size_t b_c = qsv_pad16(sizeof(double) * coef.size()), b_i = qsv_pad16(sizeof(int32_t) * PLANE_THREADS);
+    std::vector<char> image(b_c + 3 * b_i, 0);
+    memcpy(image.data(), coef.data(), sizeof(double) * coef.size());
+    memcpy(image.data() + b_c, rd0.data(), sizeof(int32_t) * PLANE_THREADS);
+    memcpy(image.data() + b_c + b_i, wr.data(), sizeof(int32_t) * PLANE_THREADS);
+    memcpy(image.data() + b_c + 2 * b_i, trip.data(), sizeof(int32_t) * trip.size());
+    StageRef staged;
+    int rc = qsvk_stage(st, image.data(), image.size(), nullptr, 0, &staged);
     if (rc) return rc;
-    char *p = reinterpret_cast<char *>(st->dev_matrix);
+    char *p = staged.dev;
     double *d_c = reinterpret_cast<double *>(p);
     int32_t *d_r = reinterpret_cast<int32_t *>(p + b_c), *d_w = reinterpret_cast<int32_t *>(p + b_c + b_i),
             *d_t = reinterpret_cast<int32_t *>(p + b_c + 2 * b_i);
-    QSV_HIP(hipMemcpyAsync(d_c, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipMemcpyAsync(d_r, rd0.data(), sizeof(int32_t) * PLANE_THREADS, hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipMemcpyAsync(d_w, wr.data(), sizeof(int32_t) * PLANE_THREADS, hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipMemcpyAsync(d_t, trip.data(), sizeof(int32_t) * trip.size(), hipMemcpyHostToDevice, st->stream));
-    QSV_HIP(hipStreamSynchronize(st->stream));  // all sources are pageable host memory that dies at return
     PlaneArgs g;
     g.batches = L / per_batch;
     g.batch_amps = static_cast<uint32_t>(used);
@@ -665,7 +666,9 @@ static int launch_plane(qsv_state *st, uint64_t d, uint64_t L, int nblocks, cons
     else if (cstride == -31) { if (nt) QSV_LAUNCH_PLANE(-31, true); else QSV_LAUNCH_PLANE(-31, false); }
     else { if (nt) QSV_LAUNCH_PLANE(0, true); else QSV_LAUNCH_PLANE(0, false); }
 #undef QSV_LAUNCH_PLANE
-    return check_launch();
+    rc = check_launch();
+    if (rc) return rc;
+    return qsvk_stage_done(st, staged);
 }
 
 int qsvq_mode2_blocks(qsv_state *st, int mode0, int mode1, int nblocks, const int32_t *sizes,
