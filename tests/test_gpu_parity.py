@@ -659,6 +659,42 @@ def test_full_size_28q_multi_qubit_kernels_round_trip_and_spot_check():
     assert abs(dev.inner(ref) - 1.0) < 1e-10
 
 
+def test_staging_ring_with_the_host_far_ahead_of_the_gpu():
+    """k = 3..6 gates, diagonals and phases queued back to back on a 24-qubit register without any host wait: each
+    kernel takes longer than the host needs to prepare the next gate, so the host laps the 8-slot staging ring of gate
+    matrices many times while the GPU is still busy.  A slot overwritten before its kernel has read it would apply a
+    wrong matrix: U_1 .. U_m followed by U_m^dagger .. U_1^dagger must restore the state, and a prefix must agree with
+    the same gates applied one by one with a synchronisation after each."""
+    n = 24
+    rng = np.random.default_rng(2424)
+    dev = DeviceState.random(n, seed=24)
+    ref = dev.copy()
+    seq = []
+    for i in range(120):
+        k = int(rng.integers(3, 7))
+        qs = [int(q) for q in rng.choice(n, size=k, replace=False)]
+        if i % 5 == 4:
+            u = np.diag(np.exp(1j * rng.uniform(0, 2 * np.pi, 1 << k)))        # table diagonal
+        elif i % 2:
+            u = np.linalg.qr(rng.standard_normal((1 << k, 1 << k)))[0]
+        else:
+            u = W.haar_unitary(1 << k, rng)
+        seq.append((u, qs))
+    slow = ref.copy()
+    for u, qs in seq[:24]:
+        slow.apply_matrix(u, qs)
+        slow.sync()
+    for i, (u, qs) in enumerate(seq):
+        dev.apply_matrix(u, qs)                         # no sync: the host runs ahead
+        if i == 23:
+            mid = dev.copy()
+    assert abs(mid.inner(slow) - 1.0) < 1e-10
+    for u, qs in reversed(seq):
+        dev.apply_matrix(np.conjugate(u).T, qs)
+    assert abs(dev.inner(ref) - 1.0) < 1e-9
+    assert abs(dev.norm2() - 1.0) < 1e-10
+
+
 def test_33_qubit_register_uses_64_bit_indices():
     """128 GiB register: amplitude indices beyond 2^32 (the 34-qubit config shards to 2^31 amplitudes per GPU; this
     exercises the same index arithmetic on one device).  Known answers only -- no host copy of the state exists."""
