@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""How far the host runs ahead of the GPU on the benchmark circuit: time to issue 100 gates against time until they are done."""
 import sys, time
-sys.path.insert(0, '/root/repo')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from quantum_computations_amd import workloads as W
 from quantum_computations_amd.device import DeviceState
 n = 28
