@@ -1576,13 +1576,12 @@ __global__ __launch_bounds__((1 << K) / ROWS * 64) void k_dense_tile(amp_t *__re
     uint64_t o[ROWS];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) o[i] = off[q * ROWS + i];
-    {
-        amp_t x[ROWS];
+    // HBM -> LDS without a stop in the registers (global_load_lds_dwordx4: lane l of the wave lands at the row's base + 16 l)
+#if defined(__HIP_DEVICE_COMPILE__)   // the builtin exists in the device pass only
 #pragma unroll
-        for (int i = 0; i < ROWS; ++i) x[i] = NT ? __builtin_nontemporal_load(a + base + o[i]) : a[base + o[i]];
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) tile[(q * ROWS + i) * 64 + lane] = x[i];
-    }
+    for (int i = 0; i < ROWS; ++i)
+        __builtin_amdgcn_global_load_lds(a + base + o[i], tile + (q * ROWS + i) * 64, 16, 0, NT ? 2 : 0);
+#endif
     __syncthreads();
     amp_t acc[ROWS];
 #pragma unroll
