@@ -462,7 +462,7 @@ def main():
                     per_kernel.setdefault(c, []).append(dev.event_elapsed_ms(2 * i, 2 * i + 1))
                 last = c
         # dominant kernel = the full-traffic dense instantiation with the most device time
-        full = {k: v for k, v in per_kernel.items() if k.startswith("k_dense<")} or per_kernel
+        full = {k: v for k, v in per_kernel.items() if k.startswith(("k_dense<", "k_dense_tile12<"))} or per_kernel
         dominant = max(full, key=lambda k: sum(full[k]))
         avg_ms = float(np.mean(full[dominant]))
         achieved = bytes_per_gate_per_gpu / (avg_ms * 1e-3) / 1e9

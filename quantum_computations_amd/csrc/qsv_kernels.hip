@@ -1608,6 +1608,36 @@ __global__ __launch_bounds__((1 << K) / ROWS * 64) void k_dense_tile(amp_t *__re
     }
 }
 
+// 1- and 2-qubit gates in the same form: one wave per input row (2 / 4 waves per workgroup), the matrix and the row
+// offsets in the kernel arguments.  On the benchmark circuit's placements 4-8 % faster than the register form (k_dense):
+// 1.28-1.34 ms against 1.31-1.48 per 1-qubit gate at n = 28, 1.36 against 1.48 on average over all pairs of bits >= 6.
+struct SmallGate {
+    double m[32];      // [row][col] (re, im), kernel index bit i <-> leg i
+    uint64_t off[4];   // amplitude offset of input / output row c
+};
+
+template <int K, bool NT>
+__global__ __launch_bounds__((1 << K) * 64) void k_dense_tile12(amp_t *__restrict__ a, const BigArgs g, const SmallGate sg) {
+    constexpr int D = 1 << K;
+    __shared__ amp_t tile[D * 64];
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t tile_id = (g.regions > 1 && gridDim.x % g.regions == 0)
+                                 ? (blockIdx.x % g.regions) * (gridDim.x / g.regions) + blockIdx.x / g.regions
+                                 : blockIdx.x;
+    amp_t *p = a + deposit(g.w0 + tile_id * 64 + lane, g) + sg.off[q];
+#if defined(__HIP_DEVICE_COMPILE__)   // the builtin exists in the device pass only
+    __builtin_amdgcn_global_load_lds(p, tile + q * 64, 16, 0, NT ? 2 : 0);
+#endif
+    __syncthreads();
+    amp_t acc = {0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+        acc = cfma(cplx{sg.m[2 * (q * D + c)], sg.m[2 * (q * D + c) + 1]}, tile[c * 64 + lane], acc);
+    if (NT) __builtin_nontemporal_store(acc, p);
+    else *p = acc;
+}
+
 template <int K, int ROWS>
 static int launch_tile_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const BigArgs &g, const double *m,
                               const uint64_t *dev_off) {
@@ -1627,6 +1657,18 @@ static int launch_tile_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const
 // contiguous windows (the d = 2^K modes of the CV path) have a clear best order per position, scattered targets
 // (fused qubit gates) are served well by 4 regions (K = 3) / 2 (K = 4) / 8 (K = 5).
 static uint32_t tile_regions(int k, const std::vector<int> &sorted_bits) {
+    if (k == 1) {   // per target bit (profiles/r02_tile_order.txt, 1-qubit section)
+        const int b = sorted_bits[0];
+        return b <= 6 ? 2 : b <= 8 ? 8 : b <= 16 ? 0 : b == 17 ? 8 : b <= 19 ? 0 : b == 20 ? 4 : b == 21 ? 8 : b <= 23 ? 4 : 0;
+    }
+    if (k == 2) {   // all 231 pairs of bits >= 6 at n = 28: 1.478 -> 1.362 ms on average with this rule
+        const int lo = sorted_bits[0], hi = sorted_bits[1];
+        if (lo <= 8) return 8;
+        if (hi >= 20 && hi <= 22) return 8;
+        if (hi == 23 && lo >= 20) return 8;
+        if (hi == 27 && lo >= 17) return 4;
+        return 0;
+    }
     const int lo = sorted_bits.front(), top = sorted_bits.back();
     const bool window = top - lo == static_cast<int>(sorted_bits.size()) - 1;
     if (k == 3) {
@@ -1639,6 +1681,53 @@ static uint32_t tile_regions(int k, const std::vector<int> &sorted_bits) {
     }
     if (!window) return 8;
     return top <= 11 ? 8 : top <= 13 ? 4 : top <= 20 ? 0 : 2;
+}
+
+static int launch_tile12(qsv_state *st, int k, const int *bits, const double *m_user) {
+    const int D = 1 << k;
+    const uint64_t W = st->amps >> k;
+    const int lowest = k == 1 ? bits[0] : std::min(bits[0], bits[1]);
+    // 2-qubit gates with a target inside a wavefront (bits 3..5) are better off with k_dense<1, 1> (1.29-1.37 ms)
+    if (lowest < (k == 1 ? 3 : QSV_LANE_BITS) || W < 64 || W % 64) return QSV_UNHANDLED_KQ;
+    SmallGate sg;
+    std::memset(&sg, 0, sizeof(sg));
+    int ui[4];
+    for (int c = 0; c < D; ++c) {
+        ui[c] = 0;
+        for (int leg = 0; leg < k; ++leg) {
+            if ((c >> leg) & 1) sg.off[c] |= 1ull << bits[leg];
+            ui[c] |= ((c >> leg) & 1) << (k - 1 - leg);
+        }
+    }
+    for (int r = 0; r < D; ++r)
+        for (int c = 0; c < D; ++c) {
+            sg.m[2 * (r * D + c)] = m_user[2 * (ui[r] * D + ui[c])];
+            sg.m[2 * (r * D + c) + 1] = m_user[2 * (ui[r] * D + ui[c]) + 1];
+        }
+    std::vector<int> sorted(bits, bits + k);
+    std::sort(sorted.begin(), sorted.end());
+    BigArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.W = W;
+    g.nins = k;
+    for (int j = 0; j < k; ++j) g.pos[j] = static_cast<uint32_t>(sorted[j]);
+    g.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : tile_regions(k, sorted);
+    const bool nt = st->nontemporal != 0;
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_tile12<%d, %s>", k, nt ? "true" : "false");
+    const uint64_t per_launch = 0x00ffffffull * 64;  // columns per dispatch
+    for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
+        const dim3 gd(static_cast<unsigned>(std::min(per_launch, g.W - g.w0) / 64)), bd(D * 64);
+        if (k == 1) {
+            if (nt) hipLaunchKernelGGL((k_dense_tile12<1, true>), gd, bd, 0, st->stream, st->data, g, sg);
+            else hipLaunchKernelGGL((k_dense_tile12<1, false>), gd, bd, 0, st->stream, st->data, g, sg);
+        } else {
+            if (nt) hipLaunchKernelGGL((k_dense_tile12<2, true>), gd, bd, 0, st->stream, st->data, g, sg);
+            else hipLaunchKernelGGL((k_dense_tile12<2, false>), gd, bd, 0, st->stream, st->data, g, sg);
+        }
+        const int rc = check_launch();
+        if (rc) return rc;
+    }
+    return QSV_OK;
 }
 
 template <int K>
@@ -1981,6 +2070,11 @@ int qsvk_dense(qsv_state *st, int k, const int *bits, int nctrl, const int *cbit
         legs.insert(legs.end(), bits, bits + k);
         const std::vector<double> full = expand_controls(k, nctrl, m_user);
         return qsvk_generic(st, k + nctrl, legs.data(), full.data());
+    }
+    // dense, uncontrolled, every target on bit 3 (1 qubit) / 6 (2 qubits) or higher: the workgroup-tile form (k_dense_tile12)
+    if (nctrl == 0 && st->unroll == 0 && st->kq_variant != 1 && st->kq_variant != 2) {
+        const int rc_tile = launch_tile12(st, k, bits, m_user);
+        if (rc_tile != QSV_UNHANDLED_KQ) return rc_tile;
     }
     GateArgs g;
     std::memset(&g, 0, sizeof(g));
