@@ -22,6 +22,7 @@ python3 $R/tools/sweep_readout.py --out $O/sweep_readout.txt --csv $O/readout_ke
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/readout_stats -- python3 $R/tools/sweep_readout.py --out $O/sweep_readout_prof.txt > $O/readout_stats.log 2>&1
 python3 $R/tools/sweep_kq.py --out $O/sweep_kq.txt > $O/sweep_kq.log 2>&1
 python3 $R/tools/sweep_default.py > $O/sweep_default.txt 2>&1
+python3 $R/tools/probe_tile_12.py 28 --pairs > $O/tile12.txt 2>&1
 python3 $R/tools/probe_fused_blocks.py 5 > $O/fused_blocks_k5.txt 2>&1
 python3 $R/tools/probe_rdm.py > $O/rdm.txt 2>&1
 # keep only the small summaries of the profiler directories (the traces are hundreds of MiB)
