@@ -1697,7 +1697,7 @@ static uint32_t tile_regions(int k, const std::vector<int> &sorted_bits) {
 
 static int launch_tile12(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits, const double *m_user) {
     const int D = 1 << k;
-    if (k + nctrl > 2 * QSV_MAX_K) return QSV_UNHANDLED_KQ;
+    if (k + nctrl > 2 * QSV_MAX_K || (nctrl && k != 1)) return QSV_UNHANDLED_KQ;   // controlled 4 x 4 gates only arise with a folded narrow control
     for (int i = 0; i < nctrl; ++i)
         if (cbits[i] < 3) return QSV_UNHANDLED_KQ;   // a control inside a 128-byte line cannot be skipped
     const uint64_t W = st->amps >> (k + nctrl);
@@ -1738,13 +1738,8 @@ static int launch_tile12(qsv_state *st, int k, const int *bits, int nctrl, const
     for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
         const dim3 gd(static_cast<unsigned>(std::min(per_launch, g.W - g.w0) / 64)), bd(D * 64);
         if (nctrl) {
-            if (k == 1) {
-                if (nt) hipLaunchKernelGGL((k_dense_tile12_ctrl<1, true>), gd, bd, 0, st->stream, st->data, g, sg);
-                else hipLaunchKernelGGL((k_dense_tile12_ctrl<1, false>), gd, bd, 0, st->stream, st->data, g, sg);
-            } else {
-                if (nt) hipLaunchKernelGGL((k_dense_tile12_ctrl<2, true>), gd, bd, 0, st->stream, st->data, g, sg);
-                else hipLaunchKernelGGL((k_dense_tile12_ctrl<2, false>), gd, bd, 0, st->stream, st->data, g, sg);
-            }
+            if (nt) hipLaunchKernelGGL((k_dense_tile12_ctrl<1, true>), gd, bd, 0, st->stream, st->data, g, sg);
+            else hipLaunchKernelGGL((k_dense_tile12_ctrl<1, false>), gd, bd, 0, st->stream, st->data, g, sg);
         } else if (k == 1) {
             if (nt) hipLaunchKernelGGL((k_dense_tile12<1, true>), gd, bd, 0, st->stream, st->data, g, sg);
             else hipLaunchKernelGGL((k_dense_tile12<1, false>), gd, bd, 0, st->stream, st->data, g, sg);
