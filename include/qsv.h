@@ -58,7 +58,9 @@ enum {
                                 the measured best per case, 1 = wave-shuffle butterflies, 2 = no exchange (per-thread
                                 strided access), 3 = line-granular exchange (address arithmetic for bits 3..5, LDS for
                                 bits 0..2), 4 = workgroup tile staged through LDS (k = 3..5, every target bit >= 3; other
-                                placements as 0), 5 = f64 matrix cores for k = 5 (k = 3, 4 as 0).  Same results; for measurements */
+                                placements as 0), 5 = f64 matrix cores for k = 5 (k = 3, 4 as 0).  Values 1 and 2 also keep
+                                1- and 2-qubit gates on the register kernels (k_dense) instead of the workgroup-tile
+                                form (k_dense_tile12).  Same results; for measurements */
     QSV_OPT_PLANE_KERNEL = 8, /* qsv_apply_mode2_blocks on the last two modes with real blocks: 1 (default) = one
                                 workgroup per (d x d) plane staged through LDS, 0 = one thread per plane */
     QSV_OPT_READOUT_VARIANT = 9 /* qsv_measure_probs / collapse / insert / permute / k-qubit diagonals: 0 (default) =
