@@ -1338,7 +1338,7 @@ int launch_dense(qsv_state *st, const GateArgs &g) {
         }
         const bool sub = g.nins > KH || g.lane_ctrl != 0;  // controlled / pair-exchange launches: plain order
         if (sub) ga.remap = 0;
-        else if (KH == 0) ga.remap = 32;
+        else if (KH == 0) ga.remap = KL == 2 ? 0 : 32;   // round 2 re-sweep (tools/probe_low_pairs.py): 1.35 against 1.41 ms
         else if (KH == 1 && KL == 0) ga.remap = top == 20 ? 0 : top == 24 ? 2 : 8;  // per-stride winners of the sweeps
         else if (KH == 1) ga.remap = far ? 0 : 8;
         else ga.remap = top < 20 ? 8 : 0;
