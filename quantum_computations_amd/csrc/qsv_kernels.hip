@@ -1307,6 +1307,7 @@ int default_unroll(const GateArgs &g) {
         while ((g.hoff[h] >> bit) > 1) ++bit;
         far = far || (bit >= 20 && bit <= 25);
     }
+    if (KH == 1 && KL == 1) return 1;   // round 2 re-sweep: one item per thread at every stride (1.35-1.44 against 1.50-1.53 ms on bits 20..25)
     if (KH == 1 && KL == 0 && far) {
         // single far pair stride: only 16 MiB (bit 20) wants four items per thread (profiles/r01_sweep_far_bits.txt)
         int bit = 0;
@@ -1340,7 +1341,7 @@ int launch_dense(qsv_state *st, const GateArgs &g) {
         if (sub) ga.remap = 0;
         else if (KH == 0) ga.remap = KL == 2 ? 0 : 32;   // round 2 re-sweep (tools/probe_low_pairs.py): 1.35 against 1.41 ms
         else if (KH == 1 && KL == 0) ga.remap = top == 20 ? 0 : top == 24 ? 2 : 8;  // per-stride winners of the sweeps
-        else if (KH == 1) ga.remap = far ? 0 : 8;
+        else if (KH == 1) ga.remap = (top == 20 || top == 24) ? 32 : 8;   // KL = 1; round 2 re-sweep (tools/probe_retune.py)
         else ga.remap = top < 20 ? 8 : 0;
     }
     while (ga.ubit > 8 && (g.W >> ga.ubit) < static_cast<uint64_t>(U)) --ga.ubit;  // small registers
