@@ -1696,6 +1696,29 @@ static uint32_t tile_regions(int k, const std::vector<int> &sorted_bits) {
     return top <= 11 ? 8 : top <= 13 ? 4 : top <= 20 ? 0 : 2;
 }
 
+// the dispatches of one tile-form gate (registers beyond 2^24 tiles take several); `sub`: the reduced-traffic symbol
+static int launch_tile12_kernels(qsv_state *st, int k, bool sub, BigArgs g, const SmallGate &sg) {
+    const bool nt = st->nontemporal != 0;
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_tile12%s<%d, %s>", sub ? "_ctrl" : "", k, nt ? "true" : "false");
+    const uint64_t per_launch = 0x00ffffffull * 64;  // columns per dispatch
+    for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
+        const dim3 gd(static_cast<unsigned>(std::min(per_launch, g.W - g.w0) / 64)), bd((1 << k) * 64);
+        if (sub) {
+            if (nt) hipLaunchKernelGGL((k_dense_tile12_ctrl<1, true>), gd, bd, 0, st->stream, st->data, g, sg);
+            else hipLaunchKernelGGL((k_dense_tile12_ctrl<1, false>), gd, bd, 0, st->stream, st->data, g, sg);
+        } else if (k == 1) {
+            if (nt) hipLaunchKernelGGL((k_dense_tile12<1, true>), gd, bd, 0, st->stream, st->data, g, sg);
+            else hipLaunchKernelGGL((k_dense_tile12<1, false>), gd, bd, 0, st->stream, st->data, g, sg);
+        } else {
+            if (nt) hipLaunchKernelGGL((k_dense_tile12<2, true>), gd, bd, 0, st->stream, st->data, g, sg);
+            else hipLaunchKernelGGL((k_dense_tile12<2, false>), gd, bd, 0, st->stream, st->data, g, sg);
+        }
+        const int rc = check_launch();
+        if (rc) return rc;
+    }
+    return QSV_OK;
+}
+
 static int launch_tile12(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits, const double *m_user) {
     const int D = 1 << k;
     if (k + nctrl > 2 * QSV_MAX_K || (nctrl && k != 1)) return QSV_UNHANDLED_KQ;   // controlled 4 x 4 gates only arise with a folded narrow control
@@ -1733,25 +1756,7 @@ static int launch_tile12(qsv_state *st, int k, const int *bits, int nctrl, const
     for (int i = 0; i < nctrl; ++i) g.or_mask |= 1ull << cbits[i];
     // controlled launches (CX on 40 random control / target pairs: 0.686 ms with 8 regions, 0.734 for k_dense_ctrl)
     g.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : nctrl ? 8 : tile_regions(k, sorted);
-    const bool nt = st->nontemporal != 0;
-    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_tile12%s<%d, %s>", nctrl ? "_ctrl" : "", k, nt ? "true" : "false");
-    const uint64_t per_launch = 0x00ffffffull * 64;  // columns per dispatch
-    for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
-        const dim3 gd(static_cast<unsigned>(std::min(per_launch, g.W - g.w0) / 64)), bd(D * 64);
-        if (nctrl) {
-            if (nt) hipLaunchKernelGGL((k_dense_tile12_ctrl<1, true>), gd, bd, 0, st->stream, st->data, g, sg);
-            else hipLaunchKernelGGL((k_dense_tile12_ctrl<1, false>), gd, bd, 0, st->stream, st->data, g, sg);
-        } else if (k == 1) {
-            if (nt) hipLaunchKernelGGL((k_dense_tile12<1, true>), gd, bd, 0, st->stream, st->data, g, sg);
-            else hipLaunchKernelGGL((k_dense_tile12<1, false>), gd, bd, 0, st->stream, st->data, g, sg);
-        } else {
-            if (nt) hipLaunchKernelGGL((k_dense_tile12<2, true>), gd, bd, 0, st->stream, st->data, g, sg);
-            else hipLaunchKernelGGL((k_dense_tile12<2, false>), gd, bd, 0, st->stream, st->data, g, sg);
-        }
-        const int rc = check_launch();
-        if (rc) return rc;
-    }
-    return QSV_OK;
+    return launch_tile12_kernels(st, k, nctrl != 0, g, sg);
 }
 
 template <int K>
@@ -2147,6 +2152,25 @@ int qsvk_dense(qsv_state *st, int k, const int *bits, int nctrl, const int *cbit
 
 // SWAP of two bits >= QSV_LANE_BITS: exchange a[base | Sa] <-> a[base | Sb]; the 00 and 11 quarters stay put.
 int qsvk_pair_exchange(qsv_state *st, int bit_a, int bit_b) {
+    const uint64_t quarter = st->amps >> 2;
+    if (st->unroll == 0 && st->kq_variant != 1 && st->kq_variant != 2 && bit_a >= 3 && bit_b >= 3 && quarter >= 64 &&
+        quarter % 64 == 0) {
+        // tile form: an X "gate" between the amplitudes with (a, b) = (1, 0) and (0, 1); both bits leave the enumeration
+        SmallGate sg;
+        std::memset(&sg, 0, sizeof(sg));
+        sg.m[2] = 1.0;   // m[0][1]
+        sg.m[4] = 1.0;   // m[1][0]
+        sg.off[0] = 1ull << bit_a;
+        sg.off[1] = 1ull << bit_b;
+        BigArgs t;
+        std::memset(&t, 0, sizeof(t));
+        t.W = quarter;
+        t.nins = 2;
+        t.pos[0] = static_cast<uint32_t>(std::min(bit_a, bit_b));
+        t.pos[1] = static_cast<uint32_t>(std::max(bit_a, bit_b));
+        t.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : 8;
+        return launch_tile12_kernels(st, 1, true, t, sg);
+    }
     GateArgs g;
     std::memset(&g, 0, sizeof(g));
     std::vector<int> removed = {bit_a, bit_b};
