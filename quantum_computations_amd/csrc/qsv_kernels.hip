@@ -493,7 +493,7 @@ struct Mfma6Args {
 };
 
 template <int K, bool NT, bool REALM>
-__global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, K == 6 ? 2 : 3))) void k_dense_mfma(
+__global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, (K == 6 && !REALM) ? 2 : 3))) void k_dense_mfma(
     amp_t *__restrict__ a, const Mfma6Args g, const double *__restrict__ Mcol,  // [plane][col][row]
     const uint64_t *__restrict__ hoff) {
     constexpr int D = 1 << K, SL = D / 4 /* k-slices */, RT = D / 16 /* row tiles */;
@@ -554,8 +554,17 @@ __global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, K 
     // (K = 6: 256 MFMAs = 7 us per tile, one tile ahead; K = 5: 64 MFMAs = 1.7 us, two ahead).  Every fetch is
     // unconditional -- past the end a wave re-reads its first tile and drops it -- because the compiler cannot count
     // loads issued under a branch and would wait for all of them (see k_rdm).
-    constexpr int NBUF = K == 6 ? 2 : 3;
+    // (a real 64 x 64 matrix halves the MFMAs: that variant is bound by memory, and three waves per SIMD without a ring
+    // -- 1.56 ms -- beat two waves with one: 1.74-1.84 ms)
+    constexpr int NBUF = K == 6 ? (REALM ? 1 : 2) : 3;
     amp_t x[NBUF][SL];
+    if constexpr (NBUF == 1) {
+        for (uint64_t tile = wave; tile < tiles; tile += waves) {
+            fetch(x[0], tile);
+            apply(x[0], tile);
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < NBUF - 1; ++b) {
         const uint64_t t = wave + b * waves;
@@ -2023,7 +2032,7 @@ static int launch_dense_mfma(qsv_state *st, int k, const int *bits, const double
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st->device);  // 256 if the query fails
     const uint64_t wave_tiles = g.W / 16;
-    const unsigned grid = static_cast<unsigned>(std::min<uint64_t>((wave_tiles + 3) / 4, (k == 6 ? 2ull : 3ull) * cus));
+    const unsigned grid = static_cast<unsigned>(std::min<uint64_t>((wave_tiles + 3) / 4, ((k == 6 && !real_matrix) ? 2ull : 3ull) * cus));
     snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_mfma<%d, %s, %s>", k, nt ? "true" : "false",
              real_matrix ? "true" : "false");
 #define QSV_LAUNCH_MFMA(KK, N, R)                                                                                  \
