@@ -554,8 +554,8 @@ __global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, (K
     // (K = 6: 256 MFMAs = 7 us per tile, one tile ahead; K = 5: 64 MFMAs = 1.7 us, two ahead).  Every fetch is
     // unconditional -- past the end a wave re-reads its first tile and drops it -- because the compiler cannot count
     // loads issued under a branch and would wait for all of them (see k_rdm).
-    // (a real 64 x 64 matrix halves the MFMAs: that variant is bound by memory, and three waves per SIMD without a ring
-    // -- 1.56 ms -- beat two waves with one: 1.74-1.84 ms)
+    // (a real 64 x 64 matrix halves the MFMAs: that variant is bound by memory and runs three waves per SIMD without a
+    // ring -- 1.74-2.04 ms by placement, the same as two waves with one (1.74-2.01), in 156 instead of 230 registers)
     constexpr int NBUF = K == 6 ? (REALM ? 1 : 2) : 3;
     amp_t x[NBUF][SL];
     if constexpr (NBUF == 1) {
