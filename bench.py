@@ -46,7 +46,9 @@ QUBITS_PER_GPU = {"cfg2": 28, "cfg3": 31, "cfg5": 27}
 DEPTH = 100
 CIRCUIT_SEED = 100
 STATE_SEED = 28
-HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); the copy rate of THIS box is measured live
+                         # (measure_copy_bandwidth) and reported beside it
+NCCL_TIMEOUT_S = 180     # a stalled collective ends the rank with a message instead of running into the driver's limit
 CPU_THREADS = 16         # the GPU box's CPU share for one GPU
 PMC_QUBITS = 28          # register size profiles/pmc_traffic.json was collected on
 
@@ -133,6 +135,43 @@ def literal_dense_baseline(n=12):
             "sample": f"expand_gate + dense mat-vec at n={n}, H and CX, median of 3", **out}
 
 
+def measure_copy_bandwidth(dev, reps=10):
+    """the fraction is reported against the 8 TB/s spec AND against what a plain copy reaches on this
+    box: the library's nontemporal copy kernel (k_copy: 1 KiB per wave-instruction, every byte read once and written
+    once -- the traffic shape of a gate) from this register into a second one of the same size, HIP events."""
+    other = dev.copy()
+    dev.copy_into(other)
+    other.sync()
+    other.timer_start()
+    for _ in range(reps):
+        dev.copy_into(other)
+    ms = other.timer_stop() / reps
+    nbytes = 2 * 16 * dev.num_amps
+    other.close()
+    return {"GBps": nbytes / (ms * 1e-3) / 1e9, "avg_ms": ms, "bytes_per_copy": nbytes, "reps": reps,
+            "kernel": "k_copy (nontemporal dwordx4 loads and stores, 16 KiB per workgroup)"}
+
+
+def gate_class_and_regime(op, n):
+    """SURVEY.md 8d buckets: gate class (dense / diag / perm) x stride regime of the target bits (low: a target inside
+    a wavefront's 1 KiB, bits 0-5; high: a target on bits >= 20, strides of 16 MiB and more; mid: the rest), and the
+    fraction of the register the specialised kernel really moves (CX, SWAP: half; CZ: a quarter)."""
+    name = op["name"]
+    bits = [n - 1 - q for q in op["indices"]]
+    m = np.asarray(op["matrix"])
+    diagonal = not np.any(m - np.diag(np.diag(m)))
+    cls = "perm" if name in ("CX", "SWAP") else "diag" if diagonal else "dense"
+    regime = "low" if min(bits) < 6 else "high" if max(bits) >= 20 else "mid"
+    moved = {"CX": 0.5, "SWAP": 0.5, "CZ": 0.25}.get(name, 1.0)
+    if name == "CZ" and min(bits) < 3:
+        moved = 0.5 if max(bits) >= 3 else 1.0      # a control inside a 128-byte line cannot be skipped
+    if name == "CX" and bits[0] < 3:
+        moved = 1.0
+    if name == "SWAP" and min(bits) < 3:
+        moved = 1.0
+    return cls, regime, moved
+
+
 # ---- config 4: the Fock-truncated CV path ---------------------------------------------------------------------------
 def run_cfg4(steps=1, n_modes=6, d=32, gates=60):
     """6 modes x cutoff 32 (2^30 amplitudes, 16 GiB), 60 gates alternating S(r = 0.1 k mod 0.5) on mode k mod 6 and
@@ -181,6 +220,11 @@ def run_cfg4(steps=1, n_modes=6, d=32, gates=60):
            "S": cls("S"), "S_on_last_mode": cls("S", lambda i: i == n_modes - 1),
            "BS": cls("BS"), "BS_interior_pairs": cls("BS", lambda i: i < n_modes - 2),
            "BS_last_pair": cls("BS", lambda i: i == n_modes - 2)}
+    # full-size parity, outside the timed region: one S on every mode and one BS on every pair of the 16 GiB register,
+    # sampled fibres / planes against U @ in computed from their own inputs (quantum_computations_amd.cv_simulator.fock)
+    spot = fock.spot_check_register(st.reg, np.random.default_rng(32))
+    out["full_size_spot_check"] = spot
+    out["max_abs_err"] = max(spot["S_max_abs_err"], spot["BS_max_abs_err"])
     del st
     return out
 
@@ -229,6 +273,18 @@ def remote_cx_pairs(n, g):
         else:
             pairs.append((glob[i % len(glob)], glob[(i + 1) % len(glob)]))
     return pairs
+
+
+def fail_rank(rank, where, dev, exc):
+    """A collective failed or timed out: report which step of which rank, then leave with a non-zero status from this
+    fresh child process (torchrun tears the other ranks down).  Nothing is re-executed or retried."""
+    stats = ""
+    if hasattr(dev, "exchanges"):
+        stats = (f"; exchange steps done {dev.exchanges}, messages sent {dev.messages}, "
+                 f"last exchange: {getattr(dev, 'last_exchange', None)}")
+    sys.stderr.write(f"bench.py: rank {rank} failed in {where}: {type(exc).__name__}: {exc}{stats}\n")
+    sys.stderr.flush()
+    os._exit(3)
 
 
 def main():
@@ -323,9 +379,14 @@ def main():
             dev.fill_random(STATE_SEED)
             reduce_device = "cpu"
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            from datetime import timedelta
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=timedelta(seconds=NCCL_TIMEOUT_S))
             dev = ShardedState.random(n, seed=STATE_SEED, device=local_rank)
-            dev.warm_up_links()                  # communicator and per-peer channel set-up stays out of the timing
+            try:
+                dev.warm_up_links()              # communicator and per-peer channel set-up stays out of the timing
+            except Exception as exc:             # first contact with the other GPUs: say where it broke, exit non-zero
+                fail_rank(rank, "link warm-up (one tiny send/recv with every peer + one all-reduce)", dev, exc)
             reduce_device = "cuda"
         barrier = dist.barrier
 
@@ -375,21 +436,26 @@ def main():
             gate.apply(dev)
             kernels.append(dev.last_kernel())
         passes[0] += 1
-    for _ in range(args.warmup):
-        step(False)
     # the event ring holds 16384 marks
     recorded_steps = min(args.steps, 16000 // (2 * len(gates)))
-    barrier()
-    torch.cuda.synchronize()
-    dev.sync()
-    t0 = time.perf_counter()
-    slot = 0
-    for k in range(args.steps):
-        slot = step(k < recorded_steps, slot)
-    dev.sync()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = reduce_max(time.perf_counter() - t0)
+    try:
+        for _ in range(args.warmup):
+            step(False)
+        barrier()
+        torch.cuda.synchronize()
+        dev.sync()
+        t0 = time.perf_counter()
+        slot = 0
+        for k in range(args.steps):
+            slot = step(k < recorded_steps, slot)
+        dev.sync()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = reduce_max(time.perf_counter() - t0)
+    except Exception as exc:
+        if world == 1:
+            raise
+        fail_rank(rank, f"pass {passes[0] + 1} of the {args.config} circuit", dev, exc)
 
     # The CPU leg and the full-size parity check run AFTER the timed region: 12 s of 16 OpenMP threads, 4 GiB host
     # arrays and their release in front of it left one launch in a few runs 18 ms long (whole-job value 892-908 instead
@@ -434,20 +500,31 @@ def main():
             "unit_note": "value = gate-apps/s on the full register x 2^(n-28): 28-qubit gate-app equivalents",
         },
         "gate_apps_per_sec_on_register": register_rate,
-        "algorithmic_GBps_per_gpu": bytes_per_gate_per_gpu * register_rate / 1e9,
+        # SURVEY.md 8d credits every gate-app with the full pass B = 2 x 16 x 2^n whatever the kernel moves (CX and
+        # SWAP touch half the register, CZ a quarter), so this figure may exceed the HBM peak; the bytes the circuit's
+        # kernels really move are given beside it
+        "full_pass_equivalent_GBps_per_gpu": bytes_per_gate_per_gpu * register_rate / 1e9,
         **extra,
     }
+    if ops and world == 1:
+        moved = sum(gate_class_and_regime(o, n)[2] for o in ops) * bytes_per_gate_per_gpu
+        result["bytes_moved_per_step"] = moved
+        result["moved_GBps_per_gpu"] = moved * args.steps / max(elapsed, 1e-12) / 1e9
     if world > 1:
-        passes = max(1, args.steps + args.warmup)
+        n_passes = max(1, args.steps + args.warmup)
         result["exchange"] = {
             "scheme": ("all rank bits swapped with the farthest-next-use local qubits in one all-to-all (grouped "
                        "send/recv over every link)" if dev.policy == "auto" and g_bits >= 2
                        else "pairwise half-shard send/recv"),
-            "steps_per_circuit": dev.exchanges / passes, "rank_bits_swapped_per_circuit": dev.qubits_exchanged / passes,
-            "local_line_up_passes_per_circuit": dev.local_swaps / passes,
-            "GiB_sent_per_rank_per_circuit": dev.bytes_sent / passes / 2**30,
-            "GiB_on_busiest_link_per_circuit": dev.link_bytes / passes / 2**30,
-            "messages_per_circuit": dev.messages / passes, "piece_GiB": min(dev.chunk_amps, 1 << n_local) * 16 / 2**30}
+            "steps_per_circuit": dev.exchanges / n_passes, "rank_bits_swapped_per_circuit": dev.qubits_exchanged / n_passes,
+            "local_line_up_passes_per_circuit": dev.local_swaps / n_passes,
+            "GiB_sent_per_rank_per_circuit": dev.bytes_sent / n_passes / 2**30,
+            "GiB_on_busiest_link_per_circuit": dev.link_bytes / n_passes / 2**30,
+            "messages_per_circuit": dev.messages / n_passes, "piece_GiB": min(dev.chunk_amps, 1 << n_local) * 16 / 2**30,
+            # gates applied slice by slice to landed data while the next slice was on the links (distributed.py)
+            "gates_inside_exchanges_per_circuit": dev.gates_in_exchanges / n_passes,
+            "launches_inside_exchanges_per_circuit": dev.rider_launches / n_passes,
+            "hardware_status": "first contact with RCCL across GPUs: rehearsed on gloo / one GPU, unmeasured before this run"}
     if recorded_steps:
         per_kernel = {}
         if world == 1:
@@ -458,7 +535,7 @@ def main():
         else:       # this rank's launches that moved nothing between GPUs (SWAPs relabel the map and launch nothing)
             last = None
             for i, (c, local) in enumerate(trace):
-                if local and c and c != "oracle-engine" and not (c == last and dev.event_elapsed_ms(2 * i, 2 * i + 1) < 1e-3):
+                if local and c and not (c == last and dev.event_elapsed_ms(2 * i, 2 * i + 1) < 1e-3):
                     per_kernel.setdefault(c, []).append(dev.event_elapsed_ms(2 * i, 2 * i + 1))
                 last = c
         # dominant kernel = the full-traffic dense instantiation with the most device time
@@ -472,13 +549,32 @@ def main():
             entry = json.loads(pmc.read_text()).get(dominant)
             if entry:
                 traffic, traffic_src = entry["hbm_bytes_per_launch"], entry["source"]
+        copy = measure_copy_bandwidth(dev) if world == 1 else None
         result["roofline"] = {
             **({"scope": "rank 0's launches of its dominant kernel, exchanges excluded"} if world > 1 else {}),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": dominant, "algorithmic_bytes_per_launch": bytes_per_gate_per_gpu,
             "avg_launch_ms": avg_ms, "launches_timed": len(full[dominant]),
+            **({"measured_copy_GBps": copy["GBps"], "frac_of_measured_copy": achieved / copy["GBps"],
+                "measured_copy": copy} if copy else {}),
         }
+        if world == 1 and ops:
+            # per-gate HIP-event times bucketed by stride regime x gate class
+            buckets = {}
+            for st_i in range(recorded_steps):
+                for i, o in enumerate(ops):
+                    cls, regime, moved = gate_class_and_regime(o, n)
+                    a = 2 * (st_i * len(gates) + i)
+                    buckets.setdefault((regime, cls), []).append((dev.event_elapsed_ms(a, a + 1), moved))
+            result["per_regime_ms"] = {
+                "regimes": "low: a target on bits 0-5 (inside a wavefront); high: a target on bits >= 20 (strides >= 16 "
+                           "MiB); mid: the rest.  classes: dense (full pass), diag (CZ: a quarter of the register), "
+                           "perm (CX, SWAP: half)",
+                **{f"{regime}/{cls}": {"launches": len(v), "avg_ms": float(np.mean([t for t, _ in v])),
+                                        "moved_GBps": float(np.mean([m for _, m in v])) * bytes_per_gate_per_gpu
+                                                      / (np.mean([t for t, _ in v]) * 1e-3) / 1e9}
+                   for (regime, cls), v in sorted(buckets.items())}}
         all_full = [t for v in full.values() for t in v]
         result["dense_full_traffic_all_kernels"] = {
             "launches": len(all_full), "avg_ms": float(np.mean(all_full)),

@@ -84,6 +84,12 @@ int qsv_create(int n_qubits, int device, qsv_state **out);
  * amplitudes always start at dev_amps; measure/insert keep them there. */
 int qsv_create_view(int n_qubits, int device, void *dev_amps, uint64_t capacity_amps, void *hip_stream,
                     qsv_state **out);
+/* Re-point a view register (one made by qsv_create_view) at another window of caller-owned device memory, with a new
+ * size: no allocation, no synchronisation -- the register's stream orders the launches on either side.  This is how the
+ * sharded register applies a gate slice by slice inside an exchange step (one handle walks the landed slices), the
+ * part of the reference's `for gate in circuit: state = gate.apply(state)` loop (dv_simulator/simulator.py:40-52) that
+ * overlaps with the transfer.  QSV_ESTATE on a register that owns its memory. */
+int qsv_rebind_view(qsv_state *st, int n_qubits, void *dev_amps, uint64_t capacity_amps);
 int qsv_destroy(qsv_state *st);
 int qsv_set_stream(qsv_state *st, void *hip_stream);
 int qsv_set_option(qsv_state *st, int option, int64_t value);

@@ -23,6 +23,7 @@ SIGNATURES: dict[str, list] = {
     "qsv_device_count": [_int_p],
     "qsv_create": [C.c_int, C.c_int, C.POINTER(_state_p)],
     "qsv_create_view": [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(_state_p)],
+    "qsv_rebind_view": [_state_p, C.c_int, C.c_void_p, C.c_uint64],
     "qsv_destroy": [_state_p],
     "qsv_set_stream": [_state_p, C.c_void_p],
     "qsv_set_option": [_state_p, C.c_int, C.c_int64],

@@ -206,6 +206,20 @@ int qsv_create_view(int n_qubits, int device, void *dev_amps, uint64_t capacity_
     return create_common(0, n_qubits, 2, 1ull << n_qubits, device, dev_amps, capacity_amps, hip_stream, out);
 }
 
+int qsv_rebind_view(qsv_state *st, int n_qubits, void *dev_amps, uint64_t capacity_amps) {
+    if (!valid(st)) return qsv_fail(QSV_EINVAL, "null state");
+    if (st->kind != 0 || st->owns_data) return qsv_fail(QSV_ESTATE, "only a qubit view register can be re-pointed");
+    if (n_qubits < 0 || n_qubits > 40) return qsv_fail(QSV_EINVAL, "n_qubits must be in 0..40");
+    if (!dev_amps) return qsv_fail(QSV_EINVAL, "null device pointer");
+    if (reinterpret_cast<uintptr_t>(dev_amps) % 16) return qsv_fail(QSV_EINVAL, "device pointer must be 16-byte aligned");
+    if (capacity_amps < (1ull << n_qubits)) return qsv_fail(QSV_EINVAL, "capacity is smaller than the register");
+    st->data = static_cast<amp_t *>(dev_amps);
+    st->capacity = capacity_amps;
+    st->n = n_qubits;
+    st->amps = 1ull << n_qubits;
+    return QSV_OK;
+}
+
 int qsv_destroy(qsv_state *st) {
     if (!st) return QSV_OK;
     (void)hipSetDevice(st->device);
@@ -363,7 +377,13 @@ int qsv_copy(qsv_state *dst, const qsv_state *src) {
     if (src->amps > dst->capacity) return qsv_fail(QSV_ENOMEM, "destination register too small");
     QSV_HIP(hipSetDevice(dst->device));
     QSV_HIP(hipStreamSynchronize(src->stream));
-    QSV_HIP(hipMemcpyAsync(dst->data, src->data, sizeof(amp_t) * src->amps, hipMemcpyDeviceToDevice, dst->stream));
+    if (dst->device == src->device) {
+        snprintf(dst->last_kernel, sizeof(dst->last_kernel), "k_copy");
+        const int rc = qsvk_copy(dst->data, src->data, src->amps, dst->stream);
+        if (rc) return rc;
+    } else {
+        QSV_HIP(hipMemcpyAsync(dst->data, src->data, sizeof(amp_t) * src->amps, hipMemcpyDeviceToDevice, dst->stream));
+    }
     dst->n = src->n;
     dst->amps = src->amps;
     return QSV_OK;

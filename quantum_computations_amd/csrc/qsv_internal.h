@@ -115,6 +115,7 @@ int qsv_fail(int code, const std::string &msg);
     } while (0)
 
 // launchers (qsv_kernels.hip / qsv_qudit.hip); all enqueue on st->stream
+int qsvk_copy(amp_t *dst, const amp_t *src, uint64_t amps, hipStream_t stream);   // nontemporal copy kernel
 int qsvk_dense(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits, const double *m_user);
 int qsvk_pair_exchange(qsv_state *st, int bit_a, int bit_b);  // SWAP on two high bits (moves 1/2 of the state)
 int qsvk_diag(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits, const double *d_user);

@@ -812,6 +812,18 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_scale(amp_t *__restrict__ a, uint
         a[i] = cmul(c, a[i]);
 }
 
+// Register-to-register copy (qsv_copy; also the "what does a plain copy reach on this box" leg of bench.py): a workgroup
+// moves 4 x 4 KiB, every wave-instruction a whole 1 KiB segment, nontemporal both ways (hipMemcpy D2D: 4.9 TB/s).
+constexpr int COPY_ITEMS = 4;
+__global__ __launch_bounds__(QSV_BLOCK) void k_copy(amp_t *__restrict__ dst, const amp_t *__restrict__ src) {
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * (QSV_BLOCK * COPY_ITEMS) + threadIdx.x;
+    amp_t v[COPY_ITEMS];
+#pragma unroll
+    for (int u = 0; u < COPY_ITEMS; ++u) v[u] = __builtin_nontemporal_load(src + base + u * QSV_BLOCK);
+#pragma unroll
+    for (int u = 0; u < COPY_ITEMS; ++u) __builtin_nontemporal_store(v[u], dst + base + u * QSV_BLOCK);
+}
+
 __global__ __launch_bounds__(QSV_BLOCK) void k_zero(amp_t *__restrict__ a, uint64_t amps, uint64_t one_at) {
     for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < amps;
          i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
@@ -1674,21 +1686,37 @@ static int launch_tile_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const
     return check_launch();
 }
 
-// Tile order of k_dense_tile by target placement (MI355X, n = 28 and 30, profiles/r02_tile_order.txt).  Which DRAM
-// channels the workgroups in flight hit together depends on the target bits; no single order wins everywhere:
-// contiguous windows (the d = 2^K modes of the CV path) have a clear best order per position, scattered targets
-// (fused qubit gates) are served well by 4 regions (K = 3) / 2 (K = 4) / 8 (K = 5).
+// Tile order of k_dense_tile / k_dense_tile12 by target placement.  Which DRAM channels the workgroups in flight hit
+// together depends on the target bits; no single order wins everywhere: contiguous windows (the d = 2^K modes of the CV
+// path) have a clear best order per position, scattered targets (fused qubit gates) are served well by 4 regions
+// (K = 3) / 2 (K = 4) / 8 (K = 5).
+// The rule is keyed on ABSOLUTE bit positions -- on the physical address bits a target toggles -- not on the distance
+// from the register's top bit: the same bits want the same order on registers of 25, 26, 27, 28, 29 and 31 qubits
+// (the shard sizes of the strong- and weak-scaling runs and of config 3; profiles/r03_tile_order_by_size.txt: bits 3-6
+// want 2 regions, 17 / 21 / 25 eight, 20 / 22 / 23 four at every size, and a pair (lo >= 17, 27) wants four regions
+// whether bit 27 is the top bit (n = 28) or not (n = 29, 31)).  Against the best of {0, 2, 4, 8, 16} regions per
+// placement the rule is within 0.7-2.5 % on the sum over the sampled placements at every size.
 static uint32_t tile_regions(int k, const std::vector<int> &sorted_bits) {
-    if (k == 1) {   // per target bit (profiles/r02_tile_order.txt, 1-qubit section)
+    if (k == 1) {   // per target bit
         const int b = sorted_bits[0];
-        return b <= 6 ? 2 : b <= 8 ? 8 : b <= 16 ? 0 : b == 17 ? 8 : b <= 19 ? 0 : b == 20 ? 4 : b == 21 ? 8 : b <= 23 ? 4 : 0;
+        return b <= 6 ? 2 : b == 7 ? 8 : b <= 16 ? 0 : b == 17 ? 8 : b <= 19 ? 0 : b == 20 ? 4 : b == 21 ? 8
+             : b <= 23 ? 4 : b == 25 ? 8 : 0;
     }
-    if (k == 2) {   // all 231 pairs of bits >= 6 at n = 28: 1.478 -> 1.362 ms on average with this rule
+    if (k == 2) {   // pairs of bits >= 6 (lower targets stay on the register form)
         const int lo = sorted_bits[0], hi = sorted_bits[1];
-        if (lo <= 8) return 8;
-        if (hi >= 20 && hi <= 22) return 8;
+        if (lo <= 8) {
+            // 8 regions, except where both strides are short: (7|8, <= 17), (6, <= 11) and (6..8, 24) run 3-12 % faster in
+            // plain order at every size
+            if ((lo >= 7 && hi <= 17) || (lo == 6 && hi <= 11) || hi == 24) return 0;
+            return 8;
+        }
+        if (hi == 20 && lo >= 12 && lo <= 16) return 0;
+        if (hi >= 20 && hi <= 21) return 8;
+        if (hi == 22) return lo >= 13 ? 4 : 8;
         if (hi == 23 && lo >= 20) return 8;
-        if (hi == 27 && lo >= 17) return 4;
+        if (hi == 24 && lo >= 18) return 4;
+        if (hi == 26 && lo == 22) return 4;
+        if ((hi == 27 && lo >= 17) || (hi == 28 && lo >= 20)) return 4;
         return 0;
     }
     const int lo = sorted_bits.front(), top = sorted_bits.back();
@@ -1709,7 +1737,10 @@ static uint32_t tile_regions(int k, const std::vector<int> &sorted_bits) {
 static int launch_tile12_kernels(qsv_state *st, int k, bool sub, BigArgs g, const SmallGate &sg) {
     const bool nt = st->nontemporal != 0;
     snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_tile12%s<%d, %s>", sub ? "_ctrl" : "", k, nt ? "true" : "false");
-    const uint64_t per_launch = 0x00ffffffull * 64;  // columns per dispatch
+    // columns per dispatch: a power of two, so that every dispatch of a split launch has a tile count the region
+    // order divides (with 2^24 - 1 tiles per dispatch a 31-qubit shard ran its 1-qubit gates in plain order: 12.0 ms
+    // on bits 3..6 against 10.9 for the register form, profiles/r03_tile_order_by_size.txt)
+    const uint64_t per_launch = (1ull << 23) * 64;
     for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
         const dim3 gd(static_cast<unsigned>(std::min(per_launch, g.W - g.w0) / 64)), bd((1 << k) * 64);
         if (sub) {
@@ -1915,7 +1946,7 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
         g.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : tile_regions(k, ins);
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_tile<%d, %d, %s, %s>", k, rows, realm ? "true" : "false",
                  nt ? "true" : "false");
-        const uint64_t per_launch = 0x00ffffffull * 64;  // columns per dispatch
+        const uint64_t per_launch = (1ull << 23) * 64;  // columns per dispatch (a power of two: see launch_tile12_kernels)
         for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
             const dim3 gd(static_cast<unsigned>(std::min(per_launch, g.W - g.w0) / 64));
             const int rc2 = k == 5 ? launch_tile_kernel<5, 8>(st, nt, realm, gd, g, dev_m, dev_off)
@@ -2613,6 +2644,21 @@ int qsvk_fill_random(qsv_state *st, uint64_t seed, uint64_t index_offset, double
 int qsvk_scale(qsv_state *st, double re, double im) {
     const int grid = grid_for(st->amps, QSV_BLOCK * 8, 8192);
     hipLaunchKernelGGL(k_scale, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, st->amps, cplx{re, im});
+    return check_launch();
+}
+
+int qsvk_copy(amp_t *dst, const amp_t *src, uint64_t amps, hipStream_t stream) {
+    constexpr uint64_t per_block = QSV_BLOCK * COPY_ITEMS;
+    const uint64_t bulk = amps / per_block * per_block;
+    for (uint64_t done = 0; done < bulk;) {   // an AQL dispatch counts work-items in 32 bits
+        const uint64_t blocks = std::min<uint64_t>((bulk - done) / per_block, 1ull << 23);
+        hipLaunchKernelGGL(k_copy, dim3(static_cast<unsigned>(blocks)), dim3(QSV_BLOCK), 0, stream, dst + done, src + done);
+        done += blocks * per_block;
+    }
+    if (bulk < amps) {
+        hipError_t e = hipMemcpyAsync(dst + bulk, src + bulk, sizeof(amp_t) * (amps - bulk), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return qsv_fail(QSV_EHIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    }
     return check_launch();
 }
 

@@ -144,3 +144,55 @@ class BS(TwoModeGate):
             state.reg.apply_two_mode_gather(cols, vals, self.index1, self.index2)
         else:
             raise ValueError(f"unknown method {self.method!r}")
+
+
+def spot_check_register(reg, rng, fibres: int = 6, planes: int = 3, r: float = 0.3, theta: float = np.pi / 4) -> dict:
+    """Size-independent amplitude check of the d-level gate kernels on a register of any size (config 4: 6 modes x
+    d = 32 = 16 GiB, where no host copy of the register is wanted): one S(r) on every mode and one BS(theta) on every
+    neighbouring pair, each compared on sampled fibres / (d, d) planes with ``U @ in`` evaluated from the sampled
+    inputs alone -- ``np.tensordot(M, T, [1, axis])`` of cv_simulator/utils.py:15,37 restricted to those fibres, the
+    plane map of cv_simulator/gates.py:58-84 restricted to those planes.  Returns the largest deviation per gate kind
+    and the kernels that ran.  The register is overwritten with seeded pseudo-random amplitudes first."""
+    n_modes, d = reg.dims
+    reg.fill_random(int(rng.integers(1, 1 << 30)))
+    out = {"S_max_abs_err": 0.0, "BS_max_abs_err": 0.0, "kernels": [], "fibres_per_mode": fibres, "planes_per_pair": planes}
+
+    def gather(index_lists):
+        return np.array([reg.download(int(i), 1)[0] for i in index_lists])
+
+    for mode in range(n_modes):
+        stride = d ** (n_modes - 1 - mode)
+        m = squeeze_matrix(d, r, 0.0)
+        bases = []
+        for _ in range(fibres):
+            left, right = int(rng.integers(0, d ** mode)), int(rng.integers(0, stride))
+            bases.append(left * d * stride + right)
+        idx = [b + a * stride for b in bases for a in range(d)]
+        before = gather(idx).reshape(fibres, d)
+        reg.apply_mode(m, mode)
+        out["kernels"].append(reg.last_kernel())
+        after = gather(idx).reshape(fibres, d)
+        out["S_max_abs_err"] = max(out["S_max_abs_err"], float(np.max(np.abs(after - before @ m.T))))
+    dense = beamsplitter_matrix(d, theta)
+    blocks = beamsplitter_blocks(d, theta)
+    for mode in range(n_modes - 1):
+        stride = d ** (n_modes - 2 - mode)
+        bases = []
+        for _ in range(planes):
+            left, right = int(rng.integers(0, d ** mode)), int(rng.integers(0, stride))
+            bases.append(left * d * d * stride + right)
+        if stride == 1:
+            before = np.array([reg.download(b, d * d) for b in bases])
+        else:
+            before = gather([b + ab * stride for b in bases for ab in range(d * d)]).reshape(planes, d * d)
+        reg.apply_two_mode_blocks(blocks, mode, mode + 1)
+        out["kernels"].append(reg.last_kernel())
+        if stride == 1:
+            after = np.array([reg.download(b, d * d) for b in bases])
+        else:
+            after = gather([b + ab * stride for b in bases for ab in range(d * d)]).reshape(planes, d * d)
+        out["BS_max_abs_err"] = max(out["BS_max_abs_err"], float(np.max(np.abs(after - before @ dense.T))))
+    out["norm2_after"] = reg.norm2()
+    out["kernels"] = sorted(set(out["kernels"]))
+    return out
+

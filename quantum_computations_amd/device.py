@@ -71,6 +71,13 @@ class DeviceState:
                   C.c_void_p(stream), C.byref(h))
         return cls(h, keepalive, int(device))
 
+    def rebind(self, n_qubits: int, dev_ptr: int, capacity_amps: int, keepalive=None) -> "DeviceState":
+        """Re-point a view register at another window of caller-owned device memory (``qsv_rebind_view``): no
+        allocation, no synchronisation.  The sharded register walks the slices of an exchange with one handle."""
+        _lib.call("qsv_rebind_view", self._h, int(n_qubits), C.c_void_p(dev_ptr), int(capacity_amps))
+        self._keepalive = keepalive
+        return self
+
     @classmethod
     def random(cls, n_qubits: int, seed: int, device: int = 0) -> "DeviceState":
         """Normalised pseudo-random ket generated on the device (counter-based, reproducible)."""
@@ -135,6 +142,11 @@ class DeviceState:
     def upload(self, amplitudes: np.ndarray, offset: int = 0) -> None:
         buf = _cbuf(amplitudes)
         _lib.call("qsv_upload", self._h, _ptr(buf), int(offset), buf.size)
+
+    def copy_into(self, other: "DeviceState") -> "DeviceState":
+        """Overwrite ``other`` (a register of at least this size on the same device) with this register."""
+        _lib.call("qsv_copy", other._h, self._h)
+        return other
 
     def copy(self) -> "DeviceState":
         other = DeviceState.zeros(DeviceState.num_qubits.fget(self), self.device)     # register qubits, whatever the view
@@ -415,6 +427,19 @@ class QuditState:
         out = np.empty(d ** n, dtype=np.complex128)
         _lib.call("qsv_download", self._h, _ptr(out), 0, out.size)
         return out.reshape((d,) * n)
+
+    def download(self, offset: int, count: int) -> np.ndarray:
+        """``count`` consecutive amplitudes starting at flat index ``offset`` (mode 0 slowest)."""
+        out = np.empty(count, dtype=np.complex128)
+        _lib.call("qsv_download", self._h, _ptr(out), int(offset), int(count))
+        return out
+
+    def fill_random(self, seed: int) -> float:
+        """Normalised pseudo-random amplitudes generated on the device (counter-based); returns the raw squared norm."""
+        n2 = C.c_double()
+        _lib.call("qsv_fill_random", self._h, int(seed), 0, C.byref(n2))
+        _lib.call("qsv_scale", self._h, 1.0 / np.sqrt(n2.value), 0.0)
+        return n2.value
 
     def upload(self, tensor: np.ndarray) -> None:
         """Overwrite the register with ``tensor`` (shape ``(d,) * n_modes`` or flat, mode 0 slowest)."""

@@ -20,6 +20,12 @@ Every exchange moves the data in pieces of at most ``chunk_amps`` amplitudes (1 
 buffer: while piece c is on the links, piece c-1 is copied into place, so the staging memory stays at 2 GiB however
 large the shard is (a 34-qubit register has 32 GiB shards).
 
+**Gates ride inside the exchange** (round 3).  A gate whose mixing legs all sit on local bits below the slice size of
+an exchange commutes with it slice by slice: ``run_circuit`` holds such gates back (they are local and would have run
+just before the exchange anyway) and ``_exchange_bits`` applies them to every slice right after it has landed, on the
+compute stream, while the next slice is on the links -- their HBM passes cost no wall time as long as they fit under the
+transfer.  ``gates_in_exchanges`` counts them.
+
 The class is written against a small "local engine" interface (the methods of ``DeviceState`` it uses) and
 against torch tensors for the exchange, so the sharding logic runs unchanged on CPU tensors with the ``gloo``
 backend in the tests (with a test-owned engine) and on HBM tensors with ``nccl`` in production.
@@ -62,6 +68,9 @@ def _restrict_leg(m: np.ndarray, k: int, leg: int, value: int) -> np.ndarray:
 
 
 CHUNK_AMPS = 1 << 26      # staging piece: 2^26 amplitudes = 1 GiB (bounded exchange buffers)
+RIDE_MIN_SLICE_AMPS = 1 << 20   # with riders an exchange is cut into at least four steps, of slices of >= 16 MiB
+RIDE_MIN_BITS = 12        # no riding in slices below 2^12 amplitudes (64 KiB): such launches only cost host time
+MAX_DEFERRED = 64         # gates held back for the next exchange at any time
 
 
 class _DryEngine:
@@ -124,6 +133,17 @@ class ShardedState:
                                                           # is what an exchange's duration is proportional to)
         self.messages = 0                                 # point-to-point messages this rank sent
         self.local_swaps = 0                              # local passes spent lining victims up for an exchange
+        self.overlap = os.environ.get("QSV_EXCHANGE_OVERLAP", "1") != "0"
+        self._host_sync = os.environ.get("QSV_EXCHANGE_HOST_SYNC", "0") == "1"   # debugging aid: drain before sending
+        self.ride_min_slice = int(os.environ.get("QSV_RIDE_MIN_SLICE_AMPS", RIDE_MIN_SLICE_AMPS))
+        self.ride_min_bits = int(os.environ.get("QSV_RIDE_MIN_BITS", RIDE_MIN_BITS))
+        self.last_exchange = None                         # description of the most recent exchange slice issued
+        self.gates_in_exchanges = 0                       # gates applied slice by slice inside exchange steps
+        self.rider_launches = 0                           # per-slice launches those gates took
+        self._deferred = []                               # gates held back by run_circuit to ride in the next exchange
+        self._apply_cb = None                             # how run_circuit's caller applies a gate (flushes use it)
+        self._advanced_already = False                    # set while held-back gates run: the plan knows them already
+        self._window_engine = None                        # engine re-pointed at one slice after the other
         self._plan = None                                 # look-ahead set by prepare(): [(indices, mixing qubits)]
         self._cursor = 0                                  # first plan entry not applied yet
         self._done = []                                   # plan entries already applied (they may arrive out of order)
@@ -266,13 +286,32 @@ class ShardedState:
         self._dist.all_reduce(t, group=self.group)
         return [float(v) for v in t.cpu()]
 
-    def _allgather_shards(self):
+    def _broadcast(self, tensor, src: int) -> None:
+        """Rank ``src``'s ``tensor`` (complex128, this register's device) to every rank, in place."""
         import torch
 
-        mine = torch.view_as_real(self.buf.contiguous())
-        shards = [torch.empty_like(mine) for _ in range(self.world)]
-        self._dist.all_gather(shards, mine, group=self.group)
-        return torch.view_as_complex(torch.cat(shards)).cpu().numpy()
+        dist = self._dist
+        root = dist.get_global_rank(self.group, src) if self.group is not None else src
+        dist.broadcast(torch.view_as_real(tensor), root, group=self.group)
+
+    def _slice_amps(self, k: int, riding: bool) -> int:
+        """Amplitudes per slice of one piece in an exchange of ``k`` rank bits: the staging piece shared by the
+        2^k - 1 peers, rounded down to a power of two; with gates riding along at least four steps (something to
+        overlap with) of slices no smaller than ``ride_min_slice``."""
+        parts = 1 << k
+        piece = 1 << (self.n_local - k)
+        cs = max(1, self.chunk_amps // (parts - 1))
+        cs = min(1 << (cs.bit_length() - 1), piece)           # power of two, so it divides the piece
+        if riding:
+            cs = min(cs, max(piece >> 2, min(piece, self.ride_min_slice)))
+        return cs
+
+    def _rider_bits(self) -> int:
+        """Local bits below this position stay inside one slice of any exchange this register may run."""
+        k = self.g if self.policy == "auto" and self.g >= 2 else 1
+        if self.n_local - k < 1:
+            return 0
+        return self._slice_amps(k, True).bit_length() - 1
 
     def _exchange_bits(self, gbits: list[int]) -> None:
         """Swap the rank bits ``gbits`` (ascending physical positions) with the top ``len(gbits)`` local bits.
@@ -282,7 +321,8 @@ class ShardedState:
         member's piece number <my gbits value> comes back into the same slot; the piece with j = my own value stays.
         k = 1 is the pairwise half-shard swap, k = g the all-to-all over every link.  The pieces travel in slices of
         at most ``chunk_amps / (2^k - 1)`` amplitudes through two staging slices: slice c is on the links while
-        slice c-1 is copied into place."""
+        slice c-1 is copied into place -- and while the gates held back by ``run_circuit`` (``_deferred``) are applied
+        to the slices that have landed."""
         k = len(gbits)
         parts = 1 << k
         piece = 1 << (self.n_local - k)
@@ -291,43 +331,166 @@ class ShardedState:
         peers = [(self.rank & ~mask) | sum(((j >> i) & 1) << (gb - self.n_local) for i, gb in enumerate(gbits))
                  for j in range(parts)]
         others = [j for j in range(parts) if j != mine]
-        cs = self.chunk_amps // (parts - 1)
-        cs = 1 << max(0, cs.bit_length() - 1)             # power of two, so it divides the piece
-        cs = min(cs, piece)
+        riders, self._deferred = self._deferred, []
+        cs = self._slice_amps(k, bool(riders))
         steps = piece // cs
         self.exchanges += 1
         self.qubits_exchanged += k
         self.bytes_sent += len(others) * piece * 16
         self.link_bytes += piece * 16
         self.messages += len(others) * steps
-        if self.buf is not None:
-            import torch
-
-            stage = len(others) * cs
-            if self._scratch is None or self._scratch.numel() < 2 * stage:
-                self._scratch = torch.empty(2 * stage, dtype=self.buf.dtype, device=self.buf.device)
-            self.local.sync()                              # the shard is final before its pieces leave
-
-            def land(step, c, half):
-                step.wait()
-                for slot, j in enumerate(others):
-                    self.buf[j * piece + c * cs:j * piece + (c + 1) * cs].copy_(half[slot * cs:(slot + 1) * cs])
-
-            pending = None
-            for c in range(steps):
-                half = self._scratch[(c & 1) * stage:(c & 1) * stage + stage]
-                sends = [(peers[j], self.buf[j * piece + c * cs:j * piece + (c + 1) * cs]) for j in others]
-                recvs = [(peers[j], half[slot * cs:(slot + 1) * cs]) for slot, j in enumerate(others)]
-                step = self._p2p(sends, recvs)             # slice c is on the links ...
-                if pending is not None:
-                    land(*pending)                         # ... while slice c-1 is copied into place
-                pending = (step, c, half)
-            land(*pending)
-        # the logical bit that lived on top-local slot i now lives on gbits[i], and vice versa
+        # the logical bit that lived on top-local slot i now lives on gbits[i], and vice versa (the riders below are
+        # resolved against the layout the landed data has)
         for i, gb in enumerate(gbits):
             slot = self.n_local - k + i
             i_slot, i_g = self.phys.index(slot), self.phys.index(gb)
             self.phys[i_slot], self.phys[i_g] = gb, slot
+        ride = self._prepare_riders(riders, cs) if riders else None
+        if self.buf is None:
+            return
+        import torch
+
+        stage = len(others) * cs
+        if self._scratch is None or self._scratch.numel() < 2 * stage:
+            self._scratch = torch.empty(2 * stage, dtype=self.buf.dtype, device=self.buf.device)
+        if self._host_sync:
+            self.local.sync()      # not needed for ordering: the collectives queue behind the current stream
+
+        def land(step, c, half):
+            step.wait()
+            for slot, j in enumerate(others):
+                self.buf[j * piece + c * cs:j * piece + (c + 1) * cs].copy_(half[slot * cs:(slot + 1) * cs])
+            if ride is not None:
+                for j in others:
+                    ride(j * piece + c * cs)
+
+        pending = None
+        for c in range(steps):
+            half = self._scratch[(c & 1) * stage:(c & 1) * stage + stage]
+            sends = [(peers[j], self.buf[j * piece + c * cs:j * piece + (c + 1) * cs]) for j in others]
+            recvs = [(peers[j], half[slot * cs:(slot + 1) * cs]) for slot, j in enumerate(others)]
+            # what a failure report names (bench.py fail_rank): the step a stalled collective belongs to
+            self.last_exchange = {"step": self.exchanges, "rank_bits": list(gbits), "slice": f"{c + 1} of {steps}",
+                                  "slice_MiB": cs * 16 / 2**20, "peers": [peers[j] for j in others]}
+            step = self._p2p(sends, recvs)             # slice c is on the links ...
+            if pending is not None:
+                land(*pending)                         # ... while slice c-1 is copied into place and takes its gates
+            if ride is not None:
+                ride(mine * piece + c * cs)            # the piece that stays: its slices take theirs along the way
+            pending = (step, c, half)
+        land(*pending)
+
+    # ---- gates that ride inside an exchange ----------------------------------------------------------
+    def _window(self, view, n_window: int):
+        """A local engine on ``view`` (a contiguous window of the shard holding 2^n_window amplitudes)."""
+        w = self._window_engine
+        if w is not None:
+            w.rebind(n_window, view.data_ptr(), view.numel(), keepalive=view)
+            return w
+        w = self._factory(view, n_window)
+        if hasattr(w, "rebind"):
+            self._window_engine = w                    # one handle walks the slices (qsv_rebind_view)
+        return w
+
+    def _prepare_riders(self, riders, cs: int):
+        """Returns ``ride(offset)``: apply every rider to the slice of ``cs`` amplitudes at ``offset`` of the shard.
+
+        A rider's legs are looked up in the layout the exchange leaves behind.  Legs on bits inside the slice are
+        real legs of the launch; the others are conserved by the gate (that is what made it a rider) and their bit
+        values are fixed over the slice -- by this rank's id (rank bits) or by the slice's offset (local bits above
+        the slice) -- so they only select a sub-block of the matrix."""
+        nw = cs.bit_length() - 1
+        prepared = []
+        for gate in riders:
+            qubits = [int(q) for q in gate.indices]
+            m = np.asarray(gate.matrix, dtype=np.complex128)
+            bits = [self._bit(q) for q in qubits]
+            if any(b >= nw for q, b in zip(qubits, bits) if q in self.mixing_qubits(gate)):
+                raise AssertionError("a deferred gate lost its place inside the slices")   # _settle_deferred guards this
+            prepared.append((m, bits, {}))
+        self.gates_in_exchanges += len(prepared)
+
+        def ride(offset: int) -> None:
+            eng = self._window(self.buf[offset:offset + cs], nw)
+            for m, bits, cache in prepared:
+                fixed = tuple(self._rank_bit(b) if b >= self.n_local else (offset >> b) & 1 if b >= nw else -1
+                              for b in bits)
+                hit = cache.get(fixed)
+                if hit is None:
+                    sub, legs = m, list(bits)
+                    j = 0
+                    for value in fixed:
+                        if value < 0:
+                            j += 1
+                        else:
+                            sub = _restrict_leg(sub, len(legs), j, value)
+                            del legs[j]
+                    if not legs:
+                        hit = ("scale", complex(sub[0, 0])) if sub[0, 0] != 1.0 else ("skip", None)
+                    elif np.array_equal(sub, np.identity(sub.shape[0])):
+                        hit = ("skip", None)
+                    else:
+                        hit = ("matrix", (sub, [nw - 1 - b for b in legs]))
+                    cache[fixed] = hit
+                kind, what = hit
+                if kind == "matrix":
+                    eng.apply_matrix(*what)
+                    self.rider_launches += 1
+                elif kind == "scale":
+                    eng.apply_scale(what)
+                    self.rider_launches += 1
+        return ride
+
+    def _can_ride(self, gate) -> bool:
+        """May ``gate`` (local in the current layout) be held back for the next exchange?  Every leg it mixes must
+        sit below the slice size; conserved legs may sit anywhere."""
+        if not self.overlap or self.world == 1 or len(self._deferred) >= MAX_DEFERRED:
+            return False
+        matrix = getattr(gate, "matrix", None)
+        mixing = self.mixing_qubits(gate)
+        if matrix is None or mixing is None or len(gate.indices) > 5:
+            return False
+        if len(gate.indices) == 2 and np.array_equal(np.asarray(matrix), _SWAP):
+            return False                                                 # a relabelling: nothing to hide
+        rb = self._rider_bits()
+        return rb >= self.ride_min_bits and all(self._bit(q) < rb for q in mixing)
+
+    def _apply_now(self, gate) -> None:
+        if self._apply_cb is not None:
+            self._apply_cb(gate)
+        else:
+            gate.apply(self)
+
+    def _flush_deferred(self, count: int | None = None, nested: bool = False) -> None:
+        """Apply the first ``count`` held-back gates (default: all) the ordinary way, in order.  ``nested``: called
+        from inside another gate's application -- the caller's per-gate callback must not be re-entered."""
+        held = self._deferred if count is None else self._deferred[:count]
+        self._deferred = [] if count is None else self._deferred[count:]
+        self._advanced_already = True          # _dispatch told the look-ahead when it held the gate back
+        try:
+            for gate in held:
+                if nested:
+                    gate.apply(self)
+                else:
+                    self._apply_now(gate)
+        finally:
+            self._advanced_already = False
+
+    def _settle_deferred(self, victims: list[int], k: int) -> None:
+        """Before an exchange of ``k`` rank bits that gives up the local bits ``victims``: held-back gates that mix
+        a qubit which is about to leave, or which no longer fits below this exchange's slice size, run now --
+        together with everything held back before them (program order among overlapping gates)."""
+        if not self._deferred:
+            return
+        nw = self._slice_amps(k, True).bit_length() - 1
+        last = -1
+        for i, gate in enumerate(self._deferred):
+            for q in self.mixing_qubits(gate):
+                b = self._bit(q)
+                if b in victims or b >= nw:
+                    last = i
+        if last >= 0:
+            self._flush_deferred(last + 1, nested=True)
 
     # ---- look-ahead: which local qubits to give up --------------------------------------------------
     @staticmethod
@@ -383,7 +546,7 @@ class ShardedState:
     PLAN_HORIZON = 4096    # how far ahead the eviction rule looks for a qubit's next use (beyond: "far")
 
     def _advance_plan(self, indices) -> None:
-        if self._plan is None:
+        if self._plan is None or self._advanced_already:
             return
         want = tuple(int(q) for q in indices)
         for step in range(self._cursor, min(len(self._plan), self._cursor + self.PLAN_WINDOW)):
@@ -432,28 +595,56 @@ class ShardedState:
         pending = deque(circuit)
         self.prepare(pending)
         order = []
-        while pending:
-            pick, used = 0, set()
-            for j, gate in enumerate(islice(pending, 256)):
-                inner = getattr(gate, "gate", gate)
-                if inner is not gate or self.mixing_qubits(gate) is None:
-                    break                                            # barriers are taken only from the front
-                qs = set(inner.indices)
-                if qs & used:
-                    break
-                used |= qs
-                if not self.needs_exchange(gate):
-                    pick = j
-                    break
-            pending.rotate(-pick)                                    # O(pick), whatever the length of the circuit
-            gate = pending.popleft()
-            pending.rotate(pick)
-            order.append(gate)
-            if apply is not None:
-                apply(gate)
-            else:
-                gate.apply(self)
+        self._apply_cb = apply
+        try:
+            while pending:
+                pick, used = 0, set()
+                for j, gate in enumerate(islice(pending, 256)):
+                    inner = getattr(gate, "gate", gate)
+                    if inner is not gate or self.mixing_qubits(gate) is None:
+                        break                                            # barriers are taken only from the front
+                    qs = set(inner.indices)
+                    if qs & used:
+                        break
+                    used |= qs
+                    if not self.needs_exchange(gate):
+                        pick = j
+                        break
+                pending.rotate(-pick)                                    # O(pick), whatever the length of the circuit
+                gate = pending.popleft()
+                pending.rotate(pick)
+                order.append(gate)
+                self._dispatch(gate)
+            self._flush_deferred()
+        finally:
+            self._apply_cb = None
         return order
+
+    def _dispatch(self, gate) -> None:
+        """Apply the gate ``run_circuit`` picked -- or hold it back: a local gate whose mixing legs all lie inside
+        the slices of an exchange runs just as well *inside* the next exchange step, slice by slice while the other
+        slices travel (``_exchange_bits``).  Held-back gates keep their order; whatever would not commute with them
+        (a gate on one of their qubits, a barrier) makes them run first."""
+        inner = getattr(gate, "gate", gate)
+        plain = inner is gate and self.mixing_qubits(gate) is not None
+        if plain and not self.needs_exchange(gate) and self._can_ride(gate):
+            # for the look-ahead the gate counts as applied: which qubits an exchange gives up -- the whole schedule
+            # -- is the same with and without riders (a rider whose qubit is chosen to leave simply runs first)
+            self._advance_plan(gate.indices)
+            self._deferred.append(gate)
+            return
+        if self._deferred:
+            if not plain:
+                self._flush_deferred()                                   # measurement, insertion, classical control
+            elif not self.needs_exchange(gate):
+                held = set()
+                for g in self._deferred:
+                    held.update(g.indices)
+                if held & set(gate.indices):
+                    self._flush_deferred()
+            # a gate that needs an exchange takes the held-back gates along: they run inside its exchange step,
+            # before its own kernel
+        self._apply_now(gate)
 
     def _choose_victims(self, count: int, avoid: set[int]) -> list[int]:
         """``count`` local bits whose qubits leave the shard, never one of ``avoid``."""
@@ -477,6 +668,7 @@ class ShardedState:
             gbits = [gbit]                                           # pairwise half-shard swap with rank r ^ bit
         k = len(gbits)
         victims = self._choose_victims(k, avoid)
+        self._settle_deferred(victims, k)
         # the pieces are contiguous only if the victims sit on the top k local bits: line them up (local passes;
         # an exchange costs 30x more).  Victims already inside the top block keep their slot.
         top = list(range(self.n_local - k, self.n_local))
@@ -729,15 +921,53 @@ class ShardedState:
         re, im = self._allreduce_sum([sign * value.real, sign * value.imag])
         return complex(re, im)
 
-    def to_numpy(self) -> np.ndarray:
-        """The whole ket in reference order, on every rank (tests and small registers only)."""
+    def to_numpy(self, root: int | None = None) -> np.ndarray | None:
+        """The whole ket in reference order as a host array: on every rank (``root=None``; tests and small
+        registers) or on rank ``root`` only (the others return ``None``).
+
+        The shards travel one after the other in pieces of at most ``chunk_amps`` amplitudes and are written straight
+        into the host array: no rank ever holds more than its own shard and one staging piece in HBM (the first form
+        concatenated the whole register on every GPU -- 256 GiB at 34 qubits).  With ``root`` given only that rank
+        allocates the 2^n host array and the pieces go point to point; otherwise every piece is a broadcast."""
         import torch
 
         self.local.sync()
-        physical = self._allgather_shards()
+        shard = 1 << self.n_local
+        piece = min(shard, self.chunk_amps)
+        keeps = root is None or self.rank == root
+        physical = np.empty(1 << self.n, dtype=np.complex128) if keeps else None
+        staging = []
+
+        def stage():
+            if not staging:
+                staging.append(torch.empty(piece, dtype=self.buf.dtype, device=self.buf.device))
+            return staging[0]
+
+        for r in range(self.world):
+            for c in range(shard // piece):
+                mine = self.buf[c * piece:(c + 1) * piece]
+                src = None
+                if root is None:
+                    src = mine if r == self.rank else stage()
+                    if self.world > 1:
+                        self._broadcast(src, r)
+                elif r == root:
+                    src = mine if self.rank == root else None
+                elif self.rank == r:
+                    self._p2p([(root, mine)], []).wait()
+                elif self.rank == root:
+                    src = stage()
+                    self._p2p([], [(r, src)]).wait()
+                if keeps and src is not None:
+                    lo = r * shard + c * piece
+                    physical[lo:lo + piece] = src.cpu().numpy()
+        if not keeps:
+            return None
         # physical[axis for bit p] -> logical: logical bit lb reads physical bit phys[lb]
         t = physical.reshape((2,) * self.n)                      # axis a <-> physical bit n-1-a
         axes = [self.n - 1 - self.phys[self.n - 1 - a] for a in range(self.n)]   # logical axis a <- physical axis
+        if axes == list(range(self.n)):
+            return physical
         return np.ascontiguousarray(t.transpose(axes)).reshape(-1)
 
     # ---- timing passthrough (bench.py) ------------------------------------------------------------

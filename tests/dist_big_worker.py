@@ -78,7 +78,8 @@ def main():
     dist.barrier()
     if rank == 0:
         print(f"dist_big_worker ok: n={n} shards of {16 * (1 << n_local) / 2**30:.0f} GiB, exchange steps={st.exchanges}, "
-              f"messages={st.messages}, GiB sent per rank={st.bytes_sent / 2**30:.1f}")
+              f"messages={st.messages}, GiB sent per rank={st.bytes_sent / 2**30:.1f}, "
+              f"gates inside exchanges={st.gates_in_exchanges} ({st.rider_launches} slice launches)")
     dist.destroy_process_group()
 
 

@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--qubits", type=int, default=9)
     ap.add_argument("--chunk-amps", type=int, default=0, help="staging piece of the exchanges (0: the 1 GiB default)")
+    ap.add_argument("--overlap-chunk-amps", type=int, default=0,
+                    help="also run the gates-inside-exchanges section, with this staging piece")
     args = ap.parse_args()
     if args.chunk_amps:
         os.environ["QSV_EXCHANGE_CHUNK_AMPS"] = str(args.chunk_amps)
@@ -138,6 +140,53 @@ def main():
     for gate in gates[1::2] + gates[0::2]:                    # every announced gate, in another order
         st._advance_plan(gate.indices)
     assert st._plan is not None and st._cursor == len(gates)
+
+    # 1c. gates riding inside the exchange steps (round 3): local gates whose mixing legs lie inside the slices are held
+    # back and applied to every slice as it lands, while the next one travels.  Same state, same exchange schedule
+    # as with the overlap switched off, and the counter shows that gates really ran in there.
+    if args.overlap_chunk_amps:
+        for seed, depth in ((31, 150), (32, 150)):
+            ops = W.random_circuit(n, depth, seed)
+            ket = W.random_ket(n, seed)
+            want, _ = O.run_circuit(ops, ket)
+            runs = {}
+            for overlap in (True, False):
+                st = make_state(n, ket, args.backend, device, chunk_amps=args.overlap_chunk_amps)
+                st.overlap, st.ride_min_bits = overlap, 1
+                out = Simulator(W.to_gates(ops)).run(st)
+                check(f"overlap={overlap} seed {seed}", out.to_numpy(), want)
+                runs[overlap] = (st.exchanges, st.bytes_sent, list(st.phys), st.gates_in_exchanges, st.rider_launches)
+                if overlap:
+                    dry = ShardedState.plan_only(n, world)
+                    dry.chunk_amps, dry.ride_min_bits = args.overlap_chunk_amps, 1
+                    dry.run_circuit(W.to_gates(ops))
+                    assert (dry.exchanges, dry.phys, dry.gates_in_exchanges) == (st.exchanges, st.phys, st.gates_in_exchanges)
+            assert runs[True][:3] == runs[False][:3], runs            # riding never changes the schedule
+            assert runs[True][3] > 0 and runs[False][3] == 0, runs
+            ridden = runs[True][3:]
+        # fused blocks and Grover's walls ride as well; a forced measurement in the middle is a barrier
+        st = make_state(n, ket, args.backend, device, chunk_amps=args.overlap_chunk_amps)
+        st.ride_min_bits = 1
+        out = Simulator(W.to_gates(ops), fuse=3).run(st)
+        check("overlap, fused blocks", out.to_numpy(), want)      # (few blocks have all their mixing legs that low)
+        ket = W.random_ket(n, 9)
+        st = make_state(n, ket, args.backend, device, chunk_amps=args.overlap_chunk_amps)
+        st.ride_min_bits = 1
+        circuit = [G.H(n - 1), G.T(n - 2), G.H(0), G.CX(n - 1, 1), G.MZ(n - 1, result=1), G.H(n - 2), G.H(1), G.H(0)]
+        sim = Simulator(circuit)
+        out = sim.run(st)
+        ops_m = [W.op("H", n - 1), W.op("T", n - 2), W.op("H", 0), W.op("CX", n - 1, 1),
+                 {"name": "M", "indices": [n - 1], "theta": 0.0, "phi": 0.0, "result": 1, "matrix": None},
+                 W.op("H", n - 2), W.op("H", 1), W.op("H", 0)]
+        want_m, _ = O.run_circuit(ops_m, ket)
+        check("overlap with a measurement barrier", out.to_numpy(), want_m)
+        # read-out on one rank only: the others get nothing, rank 1 gets the ket
+        got = out.to_numpy(root=world - 1)
+        assert (got is None) == (rank != world - 1)
+        if got is not None:
+            check("to_numpy(root)", got, want_m)
+        if rank == 0:
+            print(f"overlap ok: gates_in_exchanges={ridden[0]} rider_launches={ridden[1]}")
 
     # 2. the remote-qubit CX mix of BASELINE config 3: global->local, local->global, global->global
     ket = W.random_ket(n, 3)

@@ -2,7 +2,7 @@
 
 RCCL refuses two ranks on one device, and the development box has one GPU.  This subclass lets several ranks share
 that GPU -- HBM shards, HIP kernels, the real ``DeviceState`` engine -- by overriding only the collectives
-(``_p2p``, ``_allreduce_sum``, ``_allgather_shards``); everything else -- the slicing of the shard into pieces, the two-slice staging buffer, the copies into place, all on
+(``_p2p``, ``_allreduce_sum``, ``_broadcast``); everything else -- the slicing of the shard into pieces, the two-slice staging buffer, the copies into place, all on
 device tensors -- is ``ShardedState`` as shipped.
 """
 from __future__ import annotations
@@ -35,8 +35,8 @@ class HostStagedShardedState(ShardedState):
         dist.all_reduce(t)
         return [float(v) for v in t]
 
-    def _allgather_shards(self):
-        mine = self.buf.cpu().contiguous()
-        shards = [torch.empty_like(mine) for _ in range(self.world)]
-        dist.all_gather(shards, mine)
-        return torch.cat(shards).numpy()
+    def _broadcast(self, tensor, src):
+        host = tensor.cpu().contiguous()
+        dist.broadcast(torch.view_as_real(host), src)
+        if self.rank != src:
+            tensor.copy_(host)

@@ -1,7 +1,7 @@
 """TEST HELPER: first contact of the shipped collectives with RCCL, as far as one GPU allows.
 
 RCCL refuses two ranks on one device, so the world has ONE rank -- but ``ShardedState._p2p`` (a grouped ncclSend/ncclRecv
-of (re, im) views of slices of the complex128 shard), ``_allreduce_sum`` and ``_allgather_shards`` are the shipped
+of (re, im) views of slices of the complex128 shard), ``_allreduce_sum`` and ``_broadcast`` are the shipped
 code on HBM tensors over the real "nccl" backend: a send to self inside a group is legal in RCCL.  What this cannot
 show is a second rank; the exchange logic across ranks is covered by the gloo tests and ``tests/host_staged.py``.
 """
@@ -50,9 +50,13 @@ def main() -> int:
     torch.cuda.synchronize()
     assert np.array_equal(d1.cpu().numpy(), host[:1024]) and np.array_equal(d2.cpu().numpy(), host[2048:3072])
 
-    # (3) the scalar all-reduce and the shard all-gather
+    # (3) the scalar all-reduce, the piece broadcast and the read-out built on it
     assert st._allreduce_sum([1.5, -2.0]) == [1.5, -2.0]
-    assert np.array_equal(st._allgather_shards(), host)
+    probe = st.buf[:4096].clone()
+    st._broadcast(probe, 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(probe.cpu().numpy(), host[:4096])
+    assert np.array_equal(st.to_numpy(), host) and np.array_equal(st.to_numpy(root=0), host)
 
     # (4) a short circuit through the sharded front end on this one-rank world (no exchange, but every collective
     #     call site -- norm, measure_probs, agree_on_outcome -- runs on RCCL)

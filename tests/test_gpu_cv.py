@@ -324,3 +324,18 @@ def test_block_operator_with_unequally_spaced_elements_on_an_interior_pair(real)
             m[np.ix_(idx, idx)] = block
         want = CO.apply_two_axes(want, m, *legs)
         assert maxdiff(st.to_numpy(), want) < 1e-12, legs
+
+
+def test_cfg4_full_size_spot_check():
+    """BASELINE config 4 at its own size (6 modes x cutoff 32 = 2^30 amplitudes, 16 GiB): S(r) on every mode and
+    BS(pi/4) on every neighbouring pair, sampled fibres / planes of the register against U @ in evaluated from their own
+    inputs (no host copy of the register) -- the same check bench.py reports as ``secondary.cfg4.max_abs_err``."""
+    from quantum_computations_amd.cv_simulator import fock
+    st = fock.FockState(6, 32)
+    spot = fock.spot_check_register(st.reg, np.random.default_rng(7), fibres=8, planes=3)
+    assert spot["S_max_abs_err"] < 1e-14 and spot["BS_max_abs_err"] < 1e-14, spot
+    assert abs(spot["norm2_after"] - 1.0) < 1e-9          # exponentials of anti-hermitian truncated generators
+    names = " ".join(spot["kernels"])
+    assert "k_dense_tile<5, 8" in names and "k_mode2_blocks" in names and "k_mode2_plane" in names, names
+    del st
+

@@ -736,8 +736,12 @@ def test_sharded_state_on_one_gpu(world):
     from test_distributed_gloo import run_workers
     # staging pieces of 64 amplitudes: every exchange runs the multi-slice, double-buffered loop on device tensors
     # (slicing of the shard, two-slice staging buffer, copies into place); only the send/recv itself is host-staged
-    out = run_workers(world, "--backend", "gloo-gpu", "--qubits", "12", "--chunk-amps", "64")
+    # round 3: the same worker also holds low-bit gates back and applies them slice by slice inside the exchange steps
+    # (one view handle re-pointed at slice after slice: qsv_rebind_view), 256-amplitude staging pieces
+    out = run_workers(world, "--backend", "gloo-gpu", "--qubits", "12", "--chunk-amps", "64", "--overlap-chunk-amps", "256")
     assert f"dist_worker ok: world={world} backend=gloo-gpu" in out and "chunk_amps=64" in out
+    line = [l for l in out.splitlines() if l.startswith("overlap ok")][0]
+    assert int(line.split("gates_in_exchanges=")[1].split()[0]) > 0
 
 
 def test_shipped_collectives_on_rccl_with_one_rank():

@@ -41,7 +41,8 @@ print("# 1-qubit gate, by target bit")
 for bit in range(3, n):
     print(bit, row(dev, lambda: dev.apply_matrix(u2, [n - 1 - bit])), flush=True)
 print("# CX, by (control, target) bit")
-for c, t in [(int(c), int(t)) for c, t in (np.random.default_rng(3).choice(np.arange(3, n), 2, replace=False) for _ in range(24))]:
+cx_rng = np.random.default_rng(3)
+for c, t in [(int(c), int(t)) for c, t in (cx_rng.choice(np.arange(3, n), 2, replace=False) for _ in range(24))]:
     g = G.CX(n - 1 - c, n - 1 - t)
     print(c, t, row(dev, lambda: g.apply(dev)), flush=True)
 print("# 2-qubit gate, by (lo, hi) target bits")
