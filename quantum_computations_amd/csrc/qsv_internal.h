@@ -85,6 +85,8 @@ struct qsv_state {
     int remap = -1;                   // tile order: -1 = per-kernel default, 0 = plain, R = regions
     int kq_variant = 0;               // k = 3..5 gates: 0 = per-case choice, 1 = wave shuffles (k_dense_big<K, KL>),
                                       // 2 = no transpose (per-thread strided access), 3 = line-granular (k_dense_lds)
+    int complex_product = 0;          // complex 5- / 6-qubit blocks: 0 = three real multiplications per entry (3M),
+                                      // 4 = the four-multiplication form (measurement variant)
     int readout_variant = 0;          // measurement / insertion / permutation / table diagonals: 0 = streaming forms,
                                       // 1 = round-1 grid-stride forms
     int plane_kernel = 1;             // block-diagonal two-mode operators on the last two modes: 1 = workgroup-per-plane

@@ -16,6 +16,7 @@
 #include "qsv_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -322,7 +323,24 @@ __device__ __forceinline__ void wave_transpose(amp_t (&x)[D], const BigArgs &g, 
     }
 }
 
-template <int K, int KL, bool NT>
+// Complex matrix rows in three real multiplications per entry instead of four ("3M"): with As = Ar + Ai prepared by the
+// host and xs = xr + xi formed once per input amplitude,
+//     S1 = sum Ar xr,  S2 = sum Ai xi,  S3 = sum As xs   ->   re = S1 - S2,  im = S3 - S1 - S2.
+// A 32 x 32 complex product per amplitude is 8 flop/B -- at the chip's fp64 ridge -- so a quarter fewer FMAs is time
+// (round 3; normwise error bound as for the four-multiplication form).  A row of the matrix is three planes of D doubles.
+template <int D>
+__device__ __forceinline__ amp_t row_product_3m(const double *__restrict__ row, const amp_t (&x)[D], const double (&xs)[D]) {
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        s1 = fma(row[c], x[c].x, s1);
+        s2 = fma(row[D + c], x[c].y, s2);
+        s3 = fma(row[2 * D + c], xs[c], s3);
+    }
+    return amp_t{s1 - s2, s3 - s1 - s2};
+}
+
+template <int K, int KL, bool NT, bool M3 = false>
 __global__ __launch_bounds__(QSV_BLOCK) void k_dense_big(amp_t *__restrict__ a, const BigArgs g,
                                                         const double *__restrict__ M,
                                                         const uint64_t *__restrict__ hoff) {
@@ -340,15 +358,25 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_dense_big(amp_t *__restrict__ a, 
 #pragma unroll
     for (int c = 0; c < D; ++c) x[c] = ld<NT>(a + base + hoff[c]);
     if constexpr (KL == 0) {
+        double xs[M3 ? D : 1];
+        if constexpr (M3) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) xs[c] = x[c].x + x[c].y;
+        }
 #pragma unroll 1
         for (int r = 0; r < D; ++r) {
-            const double *row = M + 2 * D * r;
             amp_t acc = {0.0, 0.0};
+            if constexpr (M3) {
+                acc = row_product_3m<D>(M + 3 * D * r, x, xs);
+            } else {
+                const double *row = M + 2 * D * r;
 #pragma unroll
-            for (int c = 0; c < D; ++c) acc = cfma(cplx{row[2 * c], row[2 * c + 1]}, x[c], acc);
+                for (int c = 0; c < D; ++c) acc = cfma(cplx{row[2 * c], row[2 * c + 1]}, x[c], acc);
+            }
             st<NT>(a + base + hoff[r], acc);  // in place: every input of this group is already in registers
         }
     } else {
+        static_assert(!M3, "the shuffle form keeps two register arrays: no room for a third");
         const int lane = threadIdx.x & 63;
         wave_transpose<D, KL>(x, g, lane);
         amp_t y[D];
@@ -404,7 +432,7 @@ struct LdsArgs {
 // accesses (it does: they may alias) -- wave_sync() marks the spots.
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
-template <int K, int KB, bool NT, bool REALM, int BLOCK>
+template <int K, int KB, bool NT, bool REALM, int BLOCK, bool M3 = false>
 __global__ __launch_bounds__(BLOCK) void k_dense_lds(amp_t *__restrict__ a, const LdsArgs g,
                                                      const double *__restrict__ M,
                                                      const uint64_t *__restrict__ hoff) {
@@ -439,6 +467,12 @@ __global__ __launch_bounds__(BLOCK) void k_dense_lds(amp_t *__restrict__ a, cons
         }
     }
     // every thread now owns one complete group; rows of the matrix come through scalar loads
+    double xs[M3 ? D : 1];
+    if constexpr (M3) {
+        static_assert(!REALM, "a real matrix needs two multiplications per entry anyway");
+#pragma unroll
+        for (int c = 0; c < D; ++c) xs[c] = x[c].x + x[c].y;
+    }
 #pragma unroll 1
     for (int o = 0; o < D / NB; ++o) {
         if constexpr (KB > 0) wave_sync();
@@ -446,7 +480,9 @@ __global__ __launch_bounds__(BLOCK) void k_dense_lds(amp_t *__restrict__ a, cons
         for (int t = 0; t < NB; ++t) {
             const int r = o * NB + t;
             amp_t acc = {0.0, 0.0};
-            if constexpr (REALM) {
+            if constexpr (M3) {
+                acc = row_product_3m<D>(M + 3 * D * r, x, xs);
+            } else if constexpr (REALM) {
                 const double *row = M + D * r;
 #pragma unroll
                 for (int c = 0; c < D; ++c) {
@@ -492,7 +528,7 @@ struct Mfma6Args {
     uint32_t pos[8];     // ascending target bits (all >= 4)
 };
 
-template <int K, bool NT, bool REALM>
+template <int K, bool NT, bool REALM, bool M3 = false>
 __global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, (K == 6 && !REALM) ? 2 : 3))) void k_dense_mfma(
     amp_t *__restrict__ a, const Mfma6Args g, const double *__restrict__ Mcol,  // [plane][col][row]
     const uint64_t *__restrict__ hoff) {
@@ -514,7 +550,46 @@ __global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, (K
 #pragma unroll
         for (int s = 0; s < SL; ++s) x[s] = ld<NT>(a + base + off[4 * s + lk]);
     };
-    auto apply = [&](const amp_t (&x)[SL], uint64_t tile) {
+    // complex matrices in three real MFMAs per (slice, row tile) instead of four (see row_product_3m; As = Ar + Ai and
+    // xs = xr + xi are one VALU add each, next to 64-cycle MFMAs): S1 += Ar xr, S2 += Ai xi, S3 += As xs.  The row tiles
+    // are taken in two halves so that the 3 x RT / 2 accumulators stay at 48 registers.
+    auto apply3 = [&](const amp_t (&x)[SL], uint64_t tile) {
+        constexpr int HT = RT / 2;
+        const uint64_t base = deposit(tile * 16 + li, g);
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {   // not unrolled: interleaved halves need the registers of both
+            f64x4 s1[HT], s2[HT], s3[HT];
+#pragma unroll
+            for (int t = 0; t < HT; ++t) s1[t] = s2[t] = s3[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                double are[HT], aim[HT], asum[HT];
+                const double xsum = x[s].x + x[s].y;   // once per half: cheaper than 32 registers held across the tile
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    are[t] = mre[(4 * s + lk) * D + 16 * (h * HT + t) + li];
+                    aim[t] = mim[(4 * s + lk) * D + 16 * (h * HT + t) + li];
+                    asum[t] = are[t] + aim[t];
+                }
+#pragma unroll
+                for (int t = 0; t < HT; ++t) s1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[t], x[s].x, s1[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < HT; ++t) s2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[t], x[s].y, s2[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < HT; ++t) s3[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(asum[t], xsum, s3[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // in place: the wave's loads of this tile are complete (their values are MFMA operands above) before the
+            // first store issues; the second half reads only registers
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    st<NT>(a + base + off[16 * (h * HT + t) + lk + 4 * r],
+                           amp_t{s1[t][r] - s2[t][r], s3[t][r] - s1[t][r] - s2[t][r]});
+        }
+    };
+    auto apply4 = [&](const amp_t (&x)[SL], uint64_t tile) {
         f64x4 cre[RT], cim[RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t) cre[t] = cim[t] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -549,6 +624,10 @@ __global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, (K
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 st<NT>(a + base + off[16 * t + lk + 4 * r], amp_t{cre[t][r], cim[t][r]});
+    };
+    auto apply = [&](const amp_t (&x)[SL], uint64_t tile) {
+        if constexpr (M3) apply3(x, tile);
+        else apply4(x, tile);
     };
     // A ring of input buffers, no copies between them: the next tiles' loads are in flight while this tile's MFMAs run
     // (K = 6: 256 MFMAs = 7 us per tile, one tile ahead; K = 5: 64 MFMAs = 1.7 us, two ahead).  Every fetch is
@@ -812,16 +891,36 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_scale(amp_t *__restrict__ a, uint
         a[i] = cmul(c, a[i]);
 }
 
-// Register-to-register copy (qsv_copy; also the "what does a plain copy reach on this box" leg of bench.py): a workgroup
-// moves 4 x 4 KiB, every wave-instruction a whole 1 KiB segment, nontemporal both ways (hipMemcpy D2D: 4.9 TB/s).
+// Register-to-register copy (qsv_copy; also the "what does a plain copy reach on this box" leg of bench.py), every
+// wave-instruction a whole 1 KiB segment, nontemporal both ways (hipMemcpy D2D: 4.9 TB/s).  Forms (QSV_COPY_MODE, for
+// measurements; profiles/r03_copy_kernel.txt): 0 = four amplitudes per thread through registers, 1 = one amplitude per
+// thread through registers, 2 = one per thread, HBM -> LDS directly (global_load_lds_dwordx4, as the gate kernels
+// load) and LDS -> HBM.
 constexpr int COPY_ITEMS = 4;
-__global__ __launch_bounds__(QSV_BLOCK) void k_copy(amp_t *__restrict__ dst, const amp_t *__restrict__ src) {
-    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * (QSV_BLOCK * COPY_ITEMS) + threadIdx.x;
-    amp_t v[COPY_ITEMS];
+template <int MODE>
+__global__ __launch_bounds__(QSV_BLOCK) void k_copy(amp_t *__restrict__ dst, const amp_t *__restrict__ src, uint32_t regions) {
+    const uint64_t tile = (regions > 1 && gridDim.x % regions == 0)
+                              ? (blockIdx.x % regions) * static_cast<uint64_t>(gridDim.x / regions) + blockIdx.x / regions
+                              : blockIdx.x;
+    if constexpr (MODE == 0) {
+        const uint64_t base = tile * (QSV_BLOCK * COPY_ITEMS) + threadIdx.x;
+        amp_t v[COPY_ITEMS];
 #pragma unroll
-    for (int u = 0; u < COPY_ITEMS; ++u) v[u] = __builtin_nontemporal_load(src + base + u * QSV_BLOCK);
+        for (int u = 0; u < COPY_ITEMS; ++u) v[u] = __builtin_nontemporal_load(src + base + u * QSV_BLOCK);
 #pragma unroll
-    for (int u = 0; u < COPY_ITEMS; ++u) __builtin_nontemporal_store(v[u], dst + base + u * QSV_BLOCK);
+        for (int u = 0; u < COPY_ITEMS; ++u) __builtin_nontemporal_store(v[u], dst + base + u * QSV_BLOCK);
+    } else if constexpr (MODE == 1) {
+        const uint64_t i = tile * QSV_BLOCK + threadIdx.x;
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    } else {
+        __shared__ amp_t lds[QSV_BLOCK];
+        const uint64_t i = tile * QSV_BLOCK + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)   // the builtin exists in the device pass only
+        __builtin_amdgcn_global_load_lds(src + i, lds + (threadIdx.x & ~63u), 16, 0, 2);
+#endif
+        __syncthreads();
+        __builtin_nontemporal_store(lds[threadIdx.x], dst + i);
+    }
 }
 
 __global__ __launch_bounds__(QSV_BLOCK) void k_zero(amp_t *__restrict__ a, uint64_t amps, uint64_t one_at) {
@@ -1567,8 +1666,16 @@ int qsvk_adopt(qsv_state *st, uint64_t new_amps) {
 
 // k = 3..5 on any register with at least k qubits.
 template <int K, int KL>
-static void launch_big_kernel(qsv_state *st, bool nt, dim3 gd, const BigArgs &g, const double *dev_m, const uint64_t *dev_off) {
+static void launch_big_kernel(qsv_state *st, bool nt, dim3 gd, const BigArgs &g, const double *dev_m, const uint64_t *dev_off,
+                              bool m3 = false) {
     const dim3 bd(QSV_BLOCK);
+    if constexpr (K == 5 && KL == 0) {
+        if (m3) {
+            if (nt) hipLaunchKernelGGL((k_dense_big<K, KL, true, true>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
+            else hipLaunchKernelGGL((k_dense_big<K, KL, false, true>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
+            return;
+        }
+    }
     if (nt) hipLaunchKernelGGL((k_dense_big<K, KL, true>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
     else hipLaunchKernelGGL((k_dense_big<K, KL, false>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
 }
@@ -1582,10 +1689,12 @@ static void launch_big_kernel(qsv_state *st, bool nt, dim3 gd, const BigArgs &g,
 // inputs come back from LDS one 16-byte read each (lane-contiguous, conflict-free), the ROWS x 2^K slice of the matrix
 // is wave-uniform and arrives as SGPR operands.  ROWS accumulators instead of 2^K amplitudes per thread: five
 // workgroups per CU (LDS-bound at K = 5), whose load / compute / store phases overlap.
-template <int K, int ROWS, bool REAL, bool NT>
+template <int K, int ROWS, bool REAL, bool NT, bool M3 = false>
 __global__ __launch_bounds__((1 << K) / ROWS * 64) void k_dense_tile(amp_t *__restrict__ a, const BigArgs g,
                                                                      const double *__restrict__ mat,   // [q][c][ROWS]
                                                                      const uint64_t *__restrict__ off) {
+    static_assert(!(REAL && M3), "a real matrix needs two multiplications per entry anyway");
+    constexpr int PER = REAL ? 1 : M3 ? 3 : 2;   // doubles per matrix entry: re | (re, im) | (re, im, re + im)
     constexpr int D = 1 << K;
     __shared__ amp_t tile[D * 64];
     const int lane = threadIdx.x & 63;
@@ -1606,18 +1715,28 @@ __global__ __launch_bounds__((1 << K) / ROWS * 64) void k_dense_tile(amp_t *__re
 #endif
     __syncthreads();
     amp_t acc[ROWS];
+    double s3[M3 ? ROWS : 1];   // 3M form (see row_product_3m): acc.x = sum Ar xr, acc.y = sum Ai xi, s3 = sum As xs
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) acc[i] = amp_t{0.0, 0.0};
-    const double *m = mat + static_cast<size_t>(q) * D * ROWS * (REAL ? 1 : 2);
+    if constexpr (M3) {
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) s3[i] = 0.0;
+    }
+    const double *m = mat + static_cast<size_t>(q) * D * ROWS * PER;
 #pragma unroll 8
     for (int c = 0; c < D; ++c) {
         const amp_t v = tile[c * 64 + lane];
-        const double *mc = m + c * ROWS * (REAL ? 1 : 2);
+        const double *mc = m + c * ROWS * PER;
+        [[maybe_unused]] const double vs = v.x + v.y;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
             if constexpr (REAL) {
                 acc[i].x = fma(mc[i], v.x, acc[i].x);
                 acc[i].y = fma(mc[i], v.y, acc[i].y);
+            } else if constexpr (M3) {
+                acc[i].x = fma(mc[3 * i], v.x, acc[i].x);
+                acc[i].y = fma(mc[3 * i + 1], v.y, acc[i].y);
+                s3[i] = fma(mc[3 * i + 2], vs, s3[i]);
             } else {
                 acc[i] = cfma(cplx{mc[2 * i], mc[2 * i + 1]}, v, acc[i]);
             }
@@ -1625,8 +1744,10 @@ __global__ __launch_bounds__((1 << K) / ROWS * 64) void k_dense_tile(amp_t *__re
     }
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
-        if (NT) __builtin_nontemporal_store(acc[i], a + base + o[i]);
-        else a[base + o[i]] = acc[i];
+        amp_t out = acc[i];
+        if constexpr (M3) out = amp_t{acc[i].x - acc[i].y, s3[i] - acc[i].x - acc[i].y};
+        if (NT) __builtin_nontemporal_store(out, a + base + o[i]);
+        else a[base + o[i]] = out;
     }
 }
 
@@ -1674,8 +1795,15 @@ __global__ __launch_bounds__((1 << K) * 64) void k_dense_tile12_ctrl(amp_t *__re
 
 template <int K, int ROWS>
 static int launch_tile_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const BigArgs &g, const double *m,
-                              const uint64_t *dev_off) {
+                              const uint64_t *dev_off, bool m3 = false) {
     const dim3 bd((1 << K) / ROWS * 64);
+    if constexpr (K == 5) {
+        if (m3) {
+            if (nt) hipLaunchKernelGGL((k_dense_tile<K, ROWS, false, true, true>), gd, bd, 0, st->stream, st->data, g, m, dev_off);
+            else hipLaunchKernelGGL((k_dense_tile<K, ROWS, false, false, true>), gd, bd, 0, st->stream, st->data, g, m, dev_off);
+            return check_launch();
+        }
+    }
     if (nt) {
         if (realm) hipLaunchKernelGGL((k_dense_tile<K, ROWS, true, true>), gd, bd, 0, st->stream, st->data, g, m, dev_off);
         else hipLaunchKernelGGL((k_dense_tile<K, ROWS, false, true>), gd, bd, 0, st->stream, st->data, g, m, dev_off);
@@ -1800,9 +1928,10 @@ static int launch_tile12(qsv_state *st, int k, const int *bits, int nctrl, const
 }
 
 template <int K>
-static int dispatch_big(qsv_state *st, int KL, bool nt, dim3 gd, const BigArgs &g, const double *dev_m, const uint64_t *dev_off) {
+static int dispatch_big(qsv_state *st, int KL, bool nt, dim3 gd, const BigArgs &g, const double *dev_m, const uint64_t *dev_off,
+                        bool m3 = false) {
     switch (KL) {
-        case 0: launch_big_kernel<K, 0>(st, nt, gd, g, dev_m, dev_off); break;
+        case 0: launch_big_kernel<K, 0>(st, nt, gd, g, dev_m, dev_off, m3); break;
         case 1: launch_big_kernel<K, 1>(st, nt, gd, g, dev_m, dev_off); break;
         case 2: launch_big_kernel<K, 2>(st, nt, gd, g, dev_m, dev_off); break;
         case 3: launch_big_kernel<K, 3>(st, nt, gd, g, dev_m, dev_off); break;
@@ -1820,8 +1949,15 @@ static int dispatch_big(qsv_state *st, int KL, bool nt, dim3 gd, const BigArgs &
 
 template <int K, int KB, int BLOCK>
 static void launch_lds_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const LdsArgs &g, const double *dev_m,
-                              const uint64_t *dev_off) {
+                              const uint64_t *dev_off, bool m3 = false) {
     const dim3 bd(BLOCK);
+    if constexpr (K == 5) {
+        if (m3) {
+            if (nt) hipLaunchKernelGGL((k_dense_lds<K, KB, true, false, BLOCK, true>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
+            else hipLaunchKernelGGL((k_dense_lds<K, KB, false, false, BLOCK, true>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
+            return;
+        }
+    }
     if (nt) {
         if (realm) hipLaunchKernelGGL((k_dense_lds<K, KB, true, true, BLOCK>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
         else hipLaunchKernelGGL((k_dense_lds<K, KB, true, false, BLOCK>), gd, bd, 0, st->stream, st->data, g, dev_m, dev_off);
@@ -1833,12 +1969,12 @@ static void launch_lds_kernel(qsv_state *st, bool nt, bool realm, dim3 gd, const
 
 template <int K, int BLOCK>
 static int dispatch_lds(qsv_state *st, int KB, bool nt, bool realm, dim3 gd, const LdsArgs &g, const double *dev_m,
-                        const uint64_t *dev_off) {
+                        const uint64_t *dev_off, bool m3 = false) {
     switch (KB) {
-        case 0: launch_lds_kernel<K, 0, BLOCK>(st, nt, realm, gd, g, dev_m, dev_off); break;
-        case 1: launch_lds_kernel<K, 1, BLOCK>(st, nt, realm, gd, g, dev_m, dev_off); break;
-        case 2: launch_lds_kernel<K, 2, BLOCK>(st, nt, realm, gd, g, dev_m, dev_off); break;
-        default: launch_lds_kernel<K, 3, BLOCK>(st, nt, realm, gd, g, dev_m, dev_off); break;
+        case 0: launch_lds_kernel<K, 0, BLOCK>(st, nt, realm, gd, g, dev_m, dev_off, m3); break;
+        case 1: launch_lds_kernel<K, 1, BLOCK>(st, nt, realm, gd, g, dev_m, dev_off, m3); break;
+        case 2: launch_lds_kernel<K, 2, BLOCK>(st, nt, realm, gd, g, dev_m, dev_off, m3); break;
+        default: launch_lds_kernel<K, 3, BLOCK>(st, nt, realm, gd, g, dev_m, dev_off, m3); break;
     }
     return check_launch();
 }
@@ -1903,7 +2039,14 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
         return u;
     };
     const bool realm = (use_lds || use_tile) && real_matrix;
-    std::vector<double> m(realm ? static_cast<size_t>(D) * D : 2ull * D * D);
+    // complex 5-qubit blocks in three real multiplications per entry (row_product_3m): a measurement variant only
+    // (QSV_OPT_COMPLEX_PRODUCT = 3).  On the vector pipe it does not pay (profiles/r03_complex_product.txt): a quarter
+    // fewer FMAs, but a third plane of matrix rows through the scalar cache and xr + xi in 64 more registers -- 1.64-1.71
+    // ms against 1.61-1.77 for k_dense_big<5, 0>, 1.80-1.99 against 1.66-1.73 for k_dense_lds with targets inside a line
+    // (two waves per SIMD instead of three).  These kernels are not waiting for the FP64 pipe.  On the matrix cores (k = 6)
+    // the same trick is worth 13 %: see launch_dense_mfma.
+    const bool m3 = k == 5 && !real_matrix && st->complex_product == 3 && (use_tile || use_lds || KL == 0);
+    std::vector<double> m(realm ? static_cast<size_t>(D) * D : (m3 ? 3ull : 2ull) * D * D);
     std::vector<int> ui(D);
     for (int c = 0; c < D; ++c) ui[c] = user_index(c);
     for (int r = 0; r < D; ++r)
@@ -1911,6 +2054,16 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
             const int ur = ui[r], uc = ui[c];
             if (realm) {
                 m[r * D + c] = m_user[2 * (ur * D + uc)];
+            } else if (m3 && !use_tile) {   // a row = three planes of D doubles: Ar | Ai | Ar + Ai
+                const double re = m_user[2 * (ur * D + uc)], im = m_user[2 * (ur * D + uc) + 1];
+                m[3 * D * r + c] = re;
+                m[3 * D * r + D + c] = im;
+                m[3 * D * r + 2 * D + c] = re + im;
+            } else if (m3) {                // tile form: (Ar, Ai, Ar + Ai) per entry, regrouped below
+                const double re = m_user[2 * (ur * D + uc)], im = m_user[2 * (ur * D + uc) + 1];
+                m[3 * (r * D + c)] = re;
+                m[3 * (r * D + c) + 1] = im;
+                m[3 * (r * D + c) + 2] = re + im;
             } else {
                 m[2 * (r * D + c)] = m_user[2 * (ur * D + uc)];
                 m[2 * (r * D + c) + 1] = m_user[2 * (ur * D + uc) + 1];
@@ -1921,7 +2074,7 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     std::sort(ins.begin(), ins.end());
     const uint64_t W = st->amps >> k;
     if (use_tile) {  // matrix slice of wave q, input c: ROWS consecutive entries  [q][c][i] = m[q ROWS + i][c]
-        const int rows = k == 5 ? 8 : k == 4 ? 4 : 2, per = realm ? 1 : 2;
+        const int rows = k == 5 ? 8 : k == 4 ? 4 : 2, per = realm ? 1 : m3 ? 3 : 2;
         std::vector<double> mt(m.size());
         for (int r = 0; r < D; ++r)
             for (int c = 0; c < D; ++c)
@@ -1944,12 +2097,12 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
         for (size_t j = 0; j < ins.size(); ++j) g.pos[j] = static_cast<uint32_t>(ins[j]);
         const bool nt = st->nontemporal != 0;  // every wave-instruction touches whole 128-byte lines
         g.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : tile_regions(k, ins);
-        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_tile<%d, %d, %s, %s>", k, rows, realm ? "true" : "false",
-                 nt ? "true" : "false");
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_tile<%d, %d, %s, %s%s>", k, rows, realm ? "true" : "false",
+                 nt ? "true" : "false", m3 ? ", true" : "");
         const uint64_t per_launch = (1ull << 23) * 64;  // columns per dispatch (a power of two: see launch_tile12_kernels)
         for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
             const dim3 gd(static_cast<unsigned>(std::min(per_launch, g.W - g.w0) / 64));
-            const int rc2 = k == 5 ? launch_tile_kernel<5, 8>(st, nt, realm, gd, g, dev_m, dev_off)
+            const int rc2 = k == 5 ? launch_tile_kernel<5, 8>(st, nt, realm, gd, g, dev_m, dev_off, m3)
                           : k == 4 ? launch_tile_kernel<4, 4>(st, nt, realm, gd, g, dev_m, dev_off)
                                    : launch_tile_kernel<3, 2>(st, nt, realm, gd, g, dev_m, dev_off);
             if (rc2) return rc2;
@@ -1976,15 +2129,15 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
             for (int j = 0; j < KB; ++j)
                 if ((v >> j) & 1) g.bdep[v] |= 1u << low[j];
         const bool nt = st->nontemporal != 0;  // every wave-instruction touches whole 128-byte lines
-        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_lds<%d, %d, %s, %s>", k, KB, nt ? "true" : "false",
-                 realm ? "true" : "false");
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_lds<%d, %d, %s, %s%s>", k, KB, nt ? "true" : "false",
+                 realm ? "true" : "false", m3 ? ", 256, true" : "");
         g.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : 8;
         const uint64_t per_launch = 0x00ffffffull * QSV_BLOCK;  // an AQL dispatch counts work-items in 32 bits
         for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
             const dim3 gd(grid_for(std::min(per_launch, g.W - g.w0), QSV_BLOCK, 0));
             const int rc2 = k == 3 ? dispatch_lds<3, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_m, dev_off)
                           : k == 4 ? dispatch_lds<4, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_m, dev_off)
-                          : k == 5 ? dispatch_lds<5, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_m, dev_off)
+                          : k == 5 ? dispatch_lds<5, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_m, dev_off, m3)
                                    : dispatch_lds<6, QSV_BLOCK>(st, KB, nt, realm, gd, g, dev_m, dev_off);
             if (rc2) return rc2;
         }
@@ -2000,14 +2153,14 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     bool coalesced = true;
     for (int b : ins) coalesced = coalesced && b >= QSV_LANE_BITS;
     const bool nt = st->nontemporal != 0 && coalesced;
-    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_big<%d, %d, %s>", k, KL, nt ? "true" : "false");
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_big<%d, %d, %s%s>", k, KL, nt ? "true" : "false", m3 ? ", true" : "");
     g.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : 8;
     const uint64_t per_launch = 0x00ffffffull * QSV_BLOCK;  // an AQL dispatch counts work-items in 32 bits
     for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
         const dim3 gd(grid_for(std::min(per_launch, g.W - g.w0), QSV_BLOCK, 0));
         const int rc2 = k == 3 ? dispatch_big<3>(st, KL, nt, gd, g, dev_m, dev_off)
                       : k == 4 ? dispatch_big<4>(st, KL, nt, gd, g, dev_m, dev_off)
-                               : dispatch_big<5>(st, KL, nt, gd, g, dev_m, dev_off);
+                               : dispatch_big<5>(st, KL, nt, gd, g, dev_m, dev_off, m3);
         if (rc2) return rc2;
     }
     return qsvk_stage_done(st, staged);
@@ -2064,18 +2217,25 @@ static int launch_dense_mfma(qsv_state *st, int k, const int *bits, const double
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st->device);  // 256 if the query fails
     const uint64_t wave_tiles = g.W / 16;
     const unsigned grid = static_cast<unsigned>(std::min<uint64_t>((wave_tiles + 3) / 4, ((k == 6 && !real_matrix) ? 2ull : 3ull) * cus));
-    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_mfma<%d, %s, %s>", k, nt ? "true" : "false",
-             real_matrix ? "true" : "false");
-#define QSV_LAUNCH_MFMA(KK, N, R)                                                                                  \
+    const bool m3 = !real_matrix && st->complex_product != 4;   // three real MFMAs per complex entry
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_mfma<%d, %s, %s%s>", k, nt ? "true" : "false",
+             real_matrix ? "true" : "false", m3 ? ", true" : "");
+#define QSV_LAUNCH_MFMA(KK, N, ...)                                                                                \
     do {                                                                                                           \
-        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_mfma<KK, N, R>),                        \
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_mfma<KK, N, __VA_ARGS__>),              \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
-        hipLaunchKernelGGL((k_dense_mfma<KK, N, R>), dim3(grid), dim3(QSV_BLOCK), lds, st->stream, st->data, g,    \
-                           dev_m, dev_off);                                                                        \
+        hipLaunchKernelGGL((k_dense_mfma<KK, N, __VA_ARGS__>), dim3(grid), dim3(QSV_BLOCK), lds, st->stream,       \
+                           st->data, g, dev_m, dev_off);                                                           \
     } while (0)
-    if (k == 6) {
+    if (k == 6 && m3) {
+        if (nt) QSV_LAUNCH_MFMA(6, true, false, true);
+        else QSV_LAUNCH_MFMA(6, false, false, true);
+    } else if (k == 6) {
         if (nt) { if (real_matrix) QSV_LAUNCH_MFMA(6, true, true); else QSV_LAUNCH_MFMA(6, true, false); }
         else { if (real_matrix) QSV_LAUNCH_MFMA(6, false, true); else QSV_LAUNCH_MFMA(6, false, false); }
+    } else if (m3) {
+        if (nt) QSV_LAUNCH_MFMA(5, true, false, true);
+        else QSV_LAUNCH_MFMA(5, false, false, true);
     } else {
         if (nt) { if (real_matrix) QSV_LAUNCH_MFMA(5, true, true); else QSV_LAUNCH_MFMA(5, true, false); }
         else { if (real_matrix) QSV_LAUNCH_MFMA(5, false, true); else QSV_LAUNCH_MFMA(5, false, false); }
@@ -2648,11 +2808,16 @@ int qsvk_scale(qsv_state *st, double re, double im) {
 }
 
 int qsvk_copy(amp_t *dst, const amp_t *src, uint64_t amps, hipStream_t stream) {
-    constexpr uint64_t per_block = QSV_BLOCK * COPY_ITEMS;
+    static const int mode = [] { const char *e = getenv("QSV_COPY_MODE"); return e ? atoi(e) : 2; }();
+    static const int regions = [] { const char *e = getenv("QSV_COPY_REGIONS"); return e ? atoi(e) : 0; }();
+    const uint64_t per_block = mode == 0 ? QSV_BLOCK * COPY_ITEMS : QSV_BLOCK;
     const uint64_t bulk = amps / per_block * per_block;
     for (uint64_t done = 0; done < bulk;) {   // an AQL dispatch counts work-items in 32 bits
         const uint64_t blocks = std::min<uint64_t>((bulk - done) / per_block, 1ull << 23);
-        hipLaunchKernelGGL(k_copy, dim3(static_cast<unsigned>(blocks)), dim3(QSV_BLOCK), 0, stream, dst + done, src + done);
+        const dim3 gd(static_cast<unsigned>(blocks)), bd(QSV_BLOCK);
+        if (mode == 0) hipLaunchKernelGGL(k_copy<0>, gd, bd, 0, stream, dst + done, src + done, regions);
+        else if (mode == 1) hipLaunchKernelGGL(k_copy<1>, gd, bd, 0, stream, dst + done, src + done, regions);
+        else hipLaunchKernelGGL(k_copy<2>, gd, bd, 0, stream, dst + done, src + done, regions);
         done += blocks * per_block;
     }
     if (bulk < amps) {

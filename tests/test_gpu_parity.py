@@ -270,6 +270,41 @@ def test_six_qubit_gates_on_the_matrix_cores():
         assert maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL, bits
 
 
+@pytest.mark.parametrize("product", [3, 4])
+def test_complex_blocks_in_three_and_four_multiplications(product):
+    """QSV_OPT_COMPLEX_PRODUCT: complex 5- and 6-qubit blocks with three real multiplications per matrix entry (Ar xr,
+    Ai xi, (Ar + Ai)(xr + xi); shipped on the matrix cores, a measurement variant on the vector kernels) and with four,
+    in every kernel form that implements both, against the oracle."""
+    n = 16
+    rng = np.random.default_rng(30 + product)
+    ket = W.random_ket(n, 5)
+    dev = DeviceState.from_numpy(ket)
+    dev.set_option(_lib.OPT_COMPLEX_PRODUCT, product)
+    want = ket
+    seen = set()
+    for variant, cases in ((0, [[6, 8, 9, 11, 13], [0, 3, 7, 11, 15], [0, 1, 2, 7, 11], [3, 4, 5, 6, 7]]),
+                           (3, [[6, 8, 9, 11, 13], [0, 7, 11, 13, 15], [1, 2, 7, 11, 12], [0, 1, 2, 3, 4]]),
+                           (4, [[6, 8, 9, 11, 13], [3, 4, 5, 6, 7], [11, 12, 13, 14, 15]]),
+                           (5, [[6, 8, 9, 11, 13], [0, 1, 2, 3, 4], [0, 3, 7, 11, 15]]),
+                           (0, [[6, 8, 9, 11, 13, 15], [0, 1, 2, 3, 4, 5], [2, 3, 9, 4, 0, 15]])):
+        dev.set_option(_lib.OPT_KQ_VARIANT, variant)
+        for bits in cases:
+            bits = list(bits)
+            rng.shuffle(bits)
+            qs = [n - 1 - b for b in bits]
+            u = W.haar_unitary(1 << len(bits), rng)
+            dev.apply_matrix(u, qs)
+            seen.add(dev.last_kernel())
+            want = O.apply_gate(want, u, qs)
+            assert maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL, (bits, dev.last_kernel())
+    three = {"mfma6": any(x.startswith("k_dense_mfma<6, ") and x.endswith(", false, true>") for x in seen),
+             "mfma5": any(x.startswith("k_dense_mfma<5, ") and x.endswith(", false, true>") for x in seen),
+             "lds": any(x.startswith("k_dense_lds<5, ") and x.endswith(", 256, true>") for x in seen),
+             "tile": any(x.startswith("k_dense_tile<5, 8, false, ") and x.count(",") == 4 for x in seen),
+             "big": any(x.startswith("k_dense_big<5, 0, ") and x.count(",") == 3 for x in seen)}
+    assert all(three.values()) if product == 3 else not any(three.values()), (three, seen)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("k", [3, 4, 5])
 def test_register_blocked_kq_every_low_target_set(k, variant):
