@@ -280,6 +280,25 @@ int qsv_tensor_outer(int device, void *hip_stream, const void *dev_p, const void
 int qsv_tensor_axis_overlap(int device, void *hip_stream, const void *dev_z, const void *dev_t, uint64_t L, uint64_t d,
                             uint64_t R, void *dev_out);
 
+/* ---- whole circuits in one launch (registers of at most 13 qubits) ------------------------------------------------
+ * Replaces the caller loop itself -- `for gate in self.circuit: ... gate.apply(state)` with its measurement record and
+ * ClassicalControl (dv_simulator/simulator.py:40-52, :6-17) -- for the register sizes the reference can run (4..12
+ * qubits) and the batches of circuits its drivers push through a multiprocessing.Pool
+ * (impact_.../randomised_benchmarking.py:60-76, average_clifford_fidelity.py:212): one workgroup per instance keeps the
+ * register in LDS and walks its gate list; `count` instances run side by side on the CUs.  Everything is host memory,
+ * the call returns when the results are in place.
+ *   programs / prog_offsets[count + 1]: the instances' gate lists as 64-bit words (format: csrc/qsv_circuit.hip;
+ *       built by quantum_computations_amd.dv_simulator.program), word offsets per instance.
+ *   n_initial[count]; states_in + state_offsets[count + 1]: initial kets (interleaved complex128), amplitude offsets.
+ *   states_out + out_offsets[count + 1]: final kets (their sizes follow from the programs: M removes, Insert adds a qubit).
+ *   results / probabilities + result_offsets[count + 1]: outcome and the two branch norms (p0, p1) of every
+ *       measurement, in program order.  A measurement op carries either a forced outcome (gates.py:183 `result=`) or
+ *       the uniform number the host drew for it; outcome 0 iff u < p0 / (p0 + p1), as np.random.choice picks it.
+ *   max_qubits: the largest register any instance reaches (<= 13). */
+int qsv_run_programs(int device, int count, int max_qubits, const uint64_t *programs, const uint64_t *prog_offsets,
+                     const int *n_initial, const double *states_in, const uint64_t *state_offsets, double *states_out,
+                     const uint64_t *out_offsets, int *results, double *probabilities, const uint64_t *result_offsets);
+
 /* ---- timing on the state's stream (HIP events), for bench.py's roofline figures ----------- */
 int qsv_timer_start(qsv_state *st);
 int qsv_timer_stop(qsv_state *st, float *elapsed_ms); /* records, synchronises the event, returns ms */

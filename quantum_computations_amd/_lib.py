@@ -90,6 +90,8 @@ SIGNATURES: dict[str, list] = {
     "qsv_tensor_take_level": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double],
     "qsv_tensor_insert_axis": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p],
     "qsv_tensor_axis_overlap": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p],
+    "qsv_run_programs": [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "qsv_timer_start": [_state_p],
     "qsv_timer_stop": [_state_p, C.POINTER(C.c_float)],
     "qsv_last_kernel": [_state_p, C.c_char_p, C.c_size_t],

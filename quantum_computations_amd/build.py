@@ -11,7 +11,7 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_ROOT = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libqsv.so"
-SOURCES = ["qsv_api.hip", "qsv_kernels.hip", "qsv_qudit.hip", "qsv_gemm.hip", "qsv_decomp.hip"]
+SOURCES = ["qsv_api.hip", "qsv_kernels.hip", "qsv_qudit.hip", "qsv_gemm.hip", "qsv_decomp.hip", "qsv_circuit.hip"]
 HEADERS = [CSRC / "qsv_internal.h", CSRC / "qsv_linalg.h", REPO_ROOT / "include" / "qsv.h"]
 ARCH = "gfx950"
 

@@ -2808,7 +2808,7 @@ int qsvk_scale(qsv_state *st, double re, double im) {
 }
 
 int qsvk_copy(amp_t *dst, const amp_t *src, uint64_t amps, hipStream_t stream) {
-    static const int mode = [] { const char *e = getenv("QSV_COPY_MODE"); return e ? atoi(e) : 2; }();
+    static const int mode = [] { const char *e = getenv("QSV_COPY_MODE"); return e ? atoi(e) : 1; }();
     static const int regions = [] { const char *e = getenv("QSV_COPY_REGIONS"); return e ? atoi(e) : 0; }();
     const uint64_t per_block = mode == 0 ? QSV_BLOCK * COPY_ITEMS : QSV_BLOCK;
     const uint64_t bulk = amps / per_block * per_block;

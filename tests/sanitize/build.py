@@ -20,7 +20,7 @@ REPO = HERE.parent.parent
 CSRC = REPO / "quantum_computations_amd" / "csrc"
 OUT = HERE / "_build"
 CLANG = Path("/opt/rocm/lib/llvm/bin/clang++")
-SOURCES = ["qsv_api.hip", "qsv_kernels.hip", "qsv_qudit.hip", "qsv_gemm.hip", "qsv_decomp.hip"]
+SOURCES = ["qsv_api.hip", "qsv_kernels.hip", "qsv_qudit.hip", "qsv_gemm.hip", "qsv_decomp.hip", "qsv_circuit.hip"]
 SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
 INC = [f"-I{REPO / 'include'}", f"-I{CSRC}"]
 

@@ -36,6 +36,7 @@ hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::mem
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { static int token; *s = reinterpret_cast<hipStream_t>(&token); return hipSuccess; }
 
 struct StubEvent { std::chrono::steady_clock::time_point t; };
 hipError_t hipEventCreate(hipEvent_t *e) { *e = reinterpret_cast<hipEvent_t>(new StubEvent); return hipSuccess; }
