@@ -28,9 +28,9 @@
 namespace {
 
 constexpr int PROG_CHUNK = 2048;      // words (16 KiB) of program staged in LDS at a time
-constexpr int RUN_THREADS = 256;
 constexpr int RUN_MAX_QUBITS = 13;
-constexpr int OWN_MAX = (1 << RUN_MAX_QUBITS) / 2 / RUN_THREADS;   // pairs a thread owns in the two-phase ops
+// workgroup size: 256 threads up to 10 qubits (512 pairs: two per thread), 1024 above (n = 13: four pairs per thread;
+// with 256 threads a gate at n = 12 took 1.46 us, the loop over 2048 pairs being 8 trips of LDS latency)
 
 enum : uint32_t { OP_END = 0, OP_NOP = 1, OP_DENSE = 2, OP_MEASURE = 3, OP_INSERT = 4, OP_CCTRL = 5 };
 
@@ -66,6 +66,7 @@ struct RunArgs {
 };
 
 // sum of (x, y) over the workgroup, the same value in every thread (so that every thread takes the same branch on it)
+template <int RUN_THREADS>
 __device__ __forceinline__ void block_sum2(double &x, double &y, double *red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -87,7 +88,7 @@ __device__ __forceinline__ void block_sum2(double &x, double &y, double *red) {
     }
 }
 
-template <int K>
+template <int K, int RUN_THREADS>
 __device__ __forceinline__ void dense_k(amp_t *reg, int n, const uint32_t (&b)[6], const uint64_t *payload) {
     constexpr int D = 1 << K;
     // sorted target bits for the enumeration of the groups, per-column offsets in the caller's leg order
@@ -155,7 +156,9 @@ __device__ __forceinline__ void dense_k(amp_t *reg, int n, const uint32_t (&b)[6
     }
 }
 
+template <int RUN_THREADS>
 __global__ __launch_bounds__(RUN_THREADS) void k_run_programs(const RunArgs a) {
+    constexpr int OWN_MAX = (1 << RUN_MAX_QUBITS) / 2 / RUN_THREADS;   // pairs a thread owns in the two-phase ops
     extern __shared__ __attribute__((aligned(16))) char smem_run[];
     amp_t *reg = reinterpret_cast<amp_t *>(smem_run);
     uint64_t *prog = reinterpret_cast<uint64_t *>(reg + a.reg_amps);
@@ -200,10 +203,10 @@ __global__ __launch_bounds__(RUN_THREADS) void k_run_programs(const RunArgs a) {
                 skip = !(((record & pos) == pos) && ((record & neg) == 0));
             } else if (run && op == OP_DENSE) {
                 switch (k) {
-                    case 1: dense_k<1>(reg, n, b, payload); break;
-                    case 2: dense_k<2>(reg, n, b, payload); break;
-                    case 3: dense_k<3>(reg, n, b, payload); break;
-                    default: dense_k<4>(reg, n, b, payload); break;
+                    case 1: dense_k<1, RUN_THREADS>(reg, n, b, payload); break;
+                    case 2: dense_k<2, RUN_THREADS>(reg, n, b, payload); break;
+                    case 3: dense_k<3, RUN_THREADS>(reg, n, b, payload); break;
+                    default: dense_k<4, RUN_THREADS>(reg, n, b, payload); break;
                 }
                 __syncthreads();
             } else if (run && op == OP_MEASURE) {
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(RUN_THREADS) void k_run_programs(const RunArgs a) {
                     p0 += r0.x * r0.x + r0.y * r0.y;
                     p1 += r1.x * r1.x + r1.y * r1.y;
                 }
-                block_sum2(p0, p1, red);
+                block_sum2<RUN_THREADS>(p0, p1, red);
                 const int s = forced >= 0 ? static_cast<int>(forced) : (u01 < p0 / (p0 + p1) ? 0 : 1);
                 const cplx ea = s ? e10 : e00, eb = s ? e11 : e01;
                 const double scale = 1.0 / sqrt(s ? p1 : p0);
@@ -373,10 +376,16 @@ extern "C" int qsv_run_programs(int device, int count, int max_qubits, const uin
     a.probs = reinterpret_cast<double *>(pool.dev + o_prob);
     a.result_off = reinterpret_cast<const uint64_t *>(pool.dev + o_roff);
     a.reg_amps = 1u << max_qubits;
-    const size_t lds = sizeof(amp_t) * a.reg_amps + sizeof(uint64_t) * PROG_CHUNK + sizeof(double) * 2 * (RUN_THREADS / 64);
-    QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run_programs), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds)));
-    hipLaunchKernelGGL(k_run_programs, dim3(static_cast<unsigned>(count)), dim3(RUN_THREADS), lds, pool.stream, a);
+    const size_t lds = sizeof(amp_t) * a.reg_amps + sizeof(uint64_t) * PROG_CHUNK + sizeof(double) * 2 * 16;
+    if (max_qubits <= 10) {
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run_programs<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
+        hipLaunchKernelGGL(k_run_programs<256>, dim3(static_cast<unsigned>(count)), dim3(256), lds, pool.stream, a);
+    } else {
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run_programs<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
+        hipLaunchKernelGGL(k_run_programs<1024>, dim3(static_cast<unsigned>(count)), dim3(1024), lds, pool.stream, a);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return qsv_fail(QSV_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     QSV_HIP(hipMemcpyAsync(pool.host + o_out, pool.dev + o_out, total - o_out, hipMemcpyDeviceToHost, pool.stream));

@@ -42,122 +42,144 @@ class Program:
 
 def _header(op: int, k: int, length: int, bits=()) -> int:
     h = op | (k << 8) | (length << 12)
-    for j, b in enumerate(bits):
-        h |= int(b) << (28 + 6 * j)
+    shift = 28
+    for b in bits:
+        h |= b << shift
+        shift += 6
     return h
 
 
-def _doubles(values) -> np.ndarray:
-    return np.ascontiguousarray(values, dtype=np.float64).view(np.uint64)
+def _word(value: int) -> bytes:
+    return value.to_bytes(8, "little")
 
 
-def _complex_words(values) -> np.ndarray:
-    return np.ascontiguousarray(values, dtype=np.complex128).reshape(-1).view(np.float64).view(np.uint64)
+_F64 = np.dtype(np.float64)
+_C128 = np.dtype(np.complex128)
+_CONSTANT_PAYLOADS: dict[int, tuple] = {}      # id(matrix) -> (matrix, bytes): the fixed matrices of numpy_quantum only
+
+
+def _payload(matrix: np.ndarray) -> bytes:
+    """Row-major complex128 bytes of a gate matrix.  The module-level constants of numpy_quantum (H, X, CX, ...: every
+    gate object of those classes shares ONE array) are converted once."""
+    hit = _CONSTANT_PAYLOADS.get(id(matrix))
+    if hit is not None and hit[0] is matrix:
+        return hit[1]
+    if matrix.dtype != _C128 or not matrix.flags.c_contiguous:
+        matrix = np.ascontiguousarray(matrix, dtype=_C128)
+    return matrix.tobytes()
+
+
+def _register_constants() -> None:
+    from . import numpy_quantum as npq
+
+    for value in vars(npq).values():
+        if isinstance(value, np.ndarray) and value.ndim == 2 and value.shape[0] == value.shape[1] and value.shape[0] in (2, 4, 8, 16):
+            _CONSTANT_PAYLOADS[id(value)] = (value, np.ascontiguousarray(value, dtype=_C128).tobytes())
 
 
 def compile_circuit(circuit, n_initial: int) -> Program:
-    from .gates import Insert, M
+    """Encode ``circuit`` for a register of ``n_initial`` qubits.  Pure encoding, about a microsecond per gate: headers
+    and payloads are appended to one byte buffer."""
+    from .gates import Gate, Insert, M
     from .simulator import ClassicalControl
 
+    if not _CONSTANT_PAYLOADS:
+        _register_constants()
+    gate_apply = Gate.apply
     n, n_max, measured = n_initial, n_initial, 0
-    out: list[np.ndarray] = []
-    length = 0
+    buf = bytearray()
     slots: list[int] = []
     steps = []
+    chunk_bytes = 8 * CHUNK_WORDS
 
-    def emit(words: np.ndarray) -> int:
-        nonlocal length
-        room = CHUNK_WORDS - length % CHUNK_WORDS
-        if len(words) > CHUNK_WORDS:
+    def room_for(nbytes: int) -> None:
+        if nbytes > chunk_bytes:
             raise Unsupported("op larger than a program chunk")
-        if len(words) > room:                      # no op straddles a chunk: pad with one NOP
-            pad = np.zeros(room, dtype=np.uint64)
-            pad[0] = _header(OP_NOP, 0, room)
-            out.append(pad)
-            length += room
-        out.append(words)
-        length += len(words)
-        return length - len(words)
+        room = chunk_bytes - len(buf) % chunk_bytes
+        if nbytes > room:                          # no op straddles a chunk: pad with one NOP
+            buf.extend(_word(_header(OP_NOP, 0, room // 8)))
+            buf.extend(bytes(room - 8))
 
-    def encode_matrix_gate(gate) -> np.ndarray:
-        matrix, indices = getattr(gate, "matrix", None), list(getattr(gate, "indices", []))
-        if matrix is None or not isinstance(matrix, np.ndarray) or matrix.ndim != 2:
+    def matrix_gate(gate, extra: int = 0):
+        """(header, payload) of a square gate on 1..4 qubits; ``extra``: bytes emitted in front of it as one unit."""
+        matrix = getattr(gate, "matrix", None)
+        indices = getattr(gate, "indices", None)
+        if type(matrix) is not np.ndarray or matrix.ndim != 2 or type(indices) is not list:
             raise Unsupported("no matrix")
         k = len(indices)
         if k < 1 or k > MAX_GATE_QUBITS or matrix.shape != (1 << k, 1 << k):
             raise Unsupported("not a square gate on 1..4 qubits")
-        if len(set(indices)) != k or any((not isinstance(i, (int, np.integer))) or i < 0 or i >= n for i in indices):
-            raise Unsupported("indices the reference rejects")
-        if not (np.issubdtype(matrix.dtype, np.number) or matrix.dtype == bool):
+        if matrix.dtype.kind not in "biufc":
             raise Unsupported("matrix dtype")
-        words = np.empty(1 + 2 * (1 << k) ** 2, dtype=np.uint64)
-        words[0] = _header(OP_DENSE, k, len(words), [n - 1 - int(i) for i in indices])
-        words[1:] = _complex_words(matrix)
-        return words
+        bits = []
+        for i in indices:
+            if type(i) is not int:
+                if not isinstance(i, (int, np.integer)):
+                    raise Unsupported("indices the reference rejects")
+                i = int(i)
+            if i < 0 or i >= n or (n - 1 - i) in bits:
+                raise Unsupported("indices the reference rejects")
+            bits.append(n - 1 - i)
+        payload = _payload(matrix)
+        words = 1 + len(payload) // 8
+        room_for(extra + 8 * words)
+        return _word(_header(OP_DENSE, k, words, bits)), payload
 
     for entry in circuit:
-        if isinstance(entry, ClassicalControl):
+        if type(entry) is ClassicalControl:
             inner = entry.gate
-            if isinstance(inner, (M, Insert)) or isinstance(inner, ClassicalControl):
+            if isinstance(inner, (M, Insert, ClassicalControl)) or getattr(type(inner), "apply", None) is not gate_apply:
                 raise Unsupported("classical control around a size-changing gate")
             pos, neg = list(entry._pos), list(entry._neg)
             if any((not isinstance(i, (int, np.integer))) or i < 0 or i >= min(measured, 64) for i in pos + neg):
                 raise Unsupported("control index outside the measurement record")
-            body = encode_matrix_gate(inner)
-            ctrl = np.empty(3, dtype=np.uint64)
-            ctrl[0] = _header(OP_CCTRL, 0, 3)
-            ctrl[1] = sum(1 << int(i) for i in set(pos))
-            ctrl[2] = sum(1 << int(i) for i in set(neg))
-            # the control word and the gate it guards stay in one chunk: emit them as one unit
-            emit(np.concatenate([ctrl, body]))
+            head, payload = matrix_gate(inner, extra=24)     # the control word and the gate it guards: one unit
+            buf.extend(_word(_header(OP_CCTRL, 0, 3)))
+            buf.extend(_word(sum(1 << int(i) for i in set(pos))))
+            buf.extend(_word(sum(1 << int(i) for i in set(neg))))
+            buf.extend(head)
+            buf.extend(payload)
             steps.append((inner, entry, n))
-            continue
-        if isinstance(entry, M):
+        elif isinstance(entry, M):
             index = entry.indices[0]
             if n < 1 or not 0 <= index < n:
                 raise Unsupported("measured qubit outside the register")
             e0, e1 = entry.eigenvectors()
-            words = np.empty(11, dtype=np.uint64)
-            words[0] = _header(OP_MEASURE, 1, 11, [n - 1 - index])
-            words[1:5] = _complex_words(e0)
-            words[5:9] = _complex_words(e1)
-            words[9] = np.int64(-1 if entry.result is None else int(entry.result)).view(np.uint64)
-            words[10] = _doubles([0.0])[0]
-            at = emit(words)
+            room_for(88)
+            buf.extend(_word(_header(OP_MEASURE, 1, 11, [n - 1 - index])))
+            buf.extend(np.ascontiguousarray(e0, dtype=_C128).tobytes())
+            buf.extend(np.ascontiguousarray(e1, dtype=_C128).tobytes())
+            buf.extend((-1 if entry.result is None else int(entry.result)).to_bytes(8, "little", signed=True))
             if entry.result is None:
-                slots.append(at + 10)
+                slots.append(len(buf) // 8)
+            buf.extend(bytes(8))
             measured += 1
             steps.append((entry, None, n))
             n -= 1
-            continue
-        if isinstance(entry, Insert):
+        elif isinstance(entry, Insert):
             index = entry.indices[0]
             if not 0 <= index <= n:
                 raise Unsupported("insert position outside the register")
             if n + 1 > MAX_QUBITS:
                 raise Unsupported("register grows beyond the executor's size")
-            words = np.empty(5, dtype=np.uint64)
-            words[0] = _header(OP_INSERT, 1, 5, [n - index])
-            words[1:5] = _complex_words(entry.matrix[0, :])
-            emit(words)
+            room_for(40)
+            buf.extend(_word(_header(OP_INSERT, 1, 5, [n - index])))
+            buf.extend(np.ascontiguousarray(entry.matrix[0, :], dtype=_C128).tobytes())
             steps.append((entry, None, n))
             n += 1
             n_max = max(n_max, n)
-            continue
-        if getattr(type(entry), "apply", None) is not _gate_apply():
-            raise Unsupported("a gate with its own apply()")
-        emit(encode_matrix_gate(entry))
-        steps.append((entry, None, n))
-    end = np.array([_header(OP_END, 0, 1)], dtype=np.uint64)
-    emit(end)
+        else:
+            if getattr(type(entry), "apply", None) is not gate_apply:
+                raise Unsupported("a gate with its own apply()")
+            head, payload = matrix_gate(entry)
+            buf.extend(head)
+            buf.extend(payload)
+            steps.append((entry, None, n))
+    room_for(8)
+    buf.extend(_word(_header(OP_END, 0, 1)))
     if n_max > MAX_QUBITS:
         raise Unsupported("register too large")
-    return Program(np.concatenate(out), n_initial, n, n_max, measured, slots, steps)
-
-
-def _gate_apply():
-    from .gates import Gate
-    return Gate.apply
+    return Program(np.frombuffer(bytes(buf), dtype=np.uint64), n_initial, n, n_max, measured, slots, steps)
 
 
 def run_programs(programs: list[Program], kets: list[np.ndarray], device: int = 0):
@@ -175,7 +197,7 @@ def run_programs(programs: list[Program], kets: list[np.ndarray], device: int = 
         if prog.uniform_slots:
             w = w.copy()
             for slot in prog.uniform_slots:
-                w[slot] = _doubles([np.random.random_sample()])[0]
+                w[slot] = np.float64(np.random.random_sample()).view(np.uint64)
         words.append(w)
         prog_off[i + 1] = prog_off[i] + len(w)
         state_off[i + 1] = state_off[i] + (1 << prog.n_initial)

@@ -148,10 +148,10 @@ def test_run_batch_many_small_circuits_in_one_launch():
     for i in range(600):
         n = int(rng.integers(4, 11))
         ops = W.random_circuit(n, int(rng.integers(5, 60)), 1000 + i)
-        if i % 3 == 0:
-            ops.insert(len(ops) // 2, {"name": "M", "indices": [int(rng.integers(0, n))], "theta": 0.4, "phi": 0.2,
-                                       "result": int(rng.integers(0, 2)), "matrix": None})
-            ops = [o for j, o in enumerate(ops) if j <= len(ops) // 2 or max(o["indices"]) < n - 1]
+        if i % 3 == 0:                                   # a measurement in the middle, then gates on the n - 1 qubits left
+            ops.append({"name": "M", "indices": [int(rng.integers(0, n))], "theta": 0.4, "phi": 0.2,
+                        "result": int(rng.integers(0, 2)), "matrix": None})
+            ops += W.random_circuit(n - 1, int(rng.integers(5, 30)), 5000 + i)
         ket = W.random_ket(n, i)
         circuits.append(W.to_gates(ops))
         states.append(ket)

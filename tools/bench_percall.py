@@ -38,6 +38,12 @@ for n in (4, 8, 10, 12, 13, 16, 20, 24):
         batch = [circ] * 512
         kets = [ket] * 512
         many = best(lambda: Simulator.run_batch(batch, kets), 2)
-        line += (f"; in one launch {one/depth*1e6:6.3f} us per gate ({one*1e3:.2f} ms per circuit incl. compile + copies)"
-                 f"; 512 circuits in one launch {many/(512*depth)*1e6:6.3f} us per gate ({many*1e3:.1f} ms)")
+        from quantum_computations_amd.dv_simulator import program as P
+        prog = P.compile_circuit(circ, n)
+        run_only = best(lambda: P.run_programs([prog], [ket]), 5)
+        many_only = best(lambda: P.run_programs([prog] * 512, kets), 2)
+        line += (f"; in one launch {one/depth*1e6:6.3f} us per gate incl. the Python encoding of the circuit, {run_only/depth*1e6:6.3f} "
+                 f"us per gate for an encoded program ({run_only*1e3:.2f} ms per circuit incl. copies)"
+                 f"; 512 circuits in one launch {many/(512*depth)*1e6:6.3f} / {many_only/(512*depth)*1e6:6.4f} us per gate "
+                 f"({many_only*1e3:.1f} ms for {512 * depth} gates)")
     print(line, flush=True)
