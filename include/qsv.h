@@ -65,7 +65,9 @@ enum {
                                 workgroup per (d x d) plane staged through LDS, 0 = one thread per plane */
     QSV_OPT_READOUT_VARIANT = 9, /* qsv_measure_probs / collapse / insert / permute / k-qubit diagonals: 0 (default) =
                                 streaming kernels (whole 1 KiB segments per wave whatever the bit), 1 = plain
-                                grid-stride kernels (always used below 14 qubits).  Same results; for measurements */
+                                grid-stride kernels (always used below 14 qubits), 2 = as 0 but reduced density matrices
+                                with round 2's per-lane row loads (k_rdm) instead of the LDS-staged workgroup tile
+                                (k_rdm_tile).  Same results; for measurements */
     QSV_OPT_COMPLEX_PRODUCT = 10 /* complex 32 x 32 / 64 x 64 blocks (qsv_apply_kq, k = 5, 6): 0 (default) = three real
                                 multiplications per matrix entry (Ar xr, Ai xi, (Ar + Ai)(xr + xi)), 4 = four.  Equal
                                 to rounding (normwise); for measurements */

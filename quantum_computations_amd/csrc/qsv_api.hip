@@ -271,7 +271,10 @@ int qsv_set_option(qsv_state *st, int option, int64_t value) {
             st->ubit = static_cast<int>(value);
             return QSV_OK;
         case QSV_OPT_PLANE_KERNEL: st->plane_kernel = value != 0; return QSV_OK;
-        case QSV_OPT_READOUT_VARIANT: st->readout_variant = value != 0; return QSV_OK;
+        case QSV_OPT_READOUT_VARIANT:
+            if (value < 0 || value > 2) return qsv_fail(QSV_EINVAL, "read-out variant must be 0, 1 or 2");
+            st->readout_variant = static_cast<int>(value);
+            return QSV_OK;
         case QSV_OPT_COMPLEX_PRODUCT:
             if (value != 0 && value != 3 && value != 4) return qsv_fail(QSV_EINVAL, "complex product must be 0, 3 or 4");
             st->complex_product = static_cast<int>(value);

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -1306,6 +1307,155 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_rdm(const amp_t *__restrict__ a, 
     for (int e = threadIdx.x; e < P * 2 * 256; e += QSV_BLOCK) out[e] = red[e];
 }
 
+// Round 3 form of the same rank update: a WORKGROUP tile staged through LDS, so that HBM is read in whole 1 KiB
+// wave-instructions whatever the kept bits are.  k_rdm above lets lane i of the MFMA operand fetch row i itself: the 16
+// rows of a group are 2^(kept bit) apart, so with kept bits outside the lowest four every lane touches a different
+// 128-byte line (scattered kept bits [0, 5, 12, 25] at n = 28: 2.9 TB/s; k = 6: 1.9).  Here a tile is (16 T rows) x (64
+// groups).  A wave-load is 64 CONSECUTIVE amplitudes for one setting c_h of the kept bits >= 6: the lane bits carry the
+// kept bits < 6 (rows) and 6 - l free bits (groups); the 16 T loads of a tile (each wave issues 4 T of them, one tile
+// ahead, into registers) are written into the LDS tile at [row][group ^ (row & 15)] and read back as MFMA operands --
+// lane (i, kk), row tile t, step m reads [16 t + i][(4 m + kk) ^ i]: 16 distinct 16-byte columns per 16-lane group.
+// The arithmetic is cut from four to three MFMAs per (tile pair, step): with a = xr_i, b = xi_i, c = xr_j, d = xi_j
+//     P1 += a c^T,  P2 += b d^T,  P3 += (a + b)(c - d)^T      re = P1 + P2,   im = b c^T - a d^T = P3 - P1 + P2,
+// 7.5 instead of 10 MFMAs per KiB at k = 6 (the kernel that is bound by the matrix cores).  The (pair, step) units of a
+// tile are dealt to the four waves: T <= 2: four steps each, all pairs; T = 4: five pairs x eight steps each.
+struct RdmTileArgs {
+    uint64_t tiles;      // tiles of 64 S groups
+    uint64_t or_mask;    // unused (0); lets deposit() serve this struct too
+    int32_t nins;        // h: kept bits >= 6
+    uint32_t pos[8];     // those bits, ascending
+    int32_t k, l, h;     // kept bits, of which below / from bit 6
+    uint32_t lmask;      // lane bits that are kept bits
+    int32_t log_s;       // 2^k < 16: log2 of the groups sharing the 16 rows
+    uint32_t regions;    // tile order: R > 1 walks R contiguous regions of the register side by side
+    uint64_t hoff[64];   // offset of setting c_h of the kept bits >= 6 (kernel arguments: scalar loads, no upload)
+};
+
+template <int T>
+__global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, T == 4 ? 2 : 4))) void k_rdm_tile(
+    const amp_t *__restrict__ a, const RdmTileArgs g, double *__restrict__ partials) {   // [grid][P][2][256]
+    // Work split over the four waves.  T <= 2: four of the sixteen steps each, every tile pair.  T = 4 (ten pairs: all of
+    // them would be 240 accumulator registers): five pairs x eight steps.  Both halves run the SAME code on the pair list
+    // A = {(0,0), (2,2), (0,1), (2,3), (0,2)} of operand slots; the second half fills slot tt with row tile tt + 1 mod 4
+    // and so computes (1,1), (3,3), (1,2), (3,0), (1,3) -- the complement (the cyclic shift maps A onto it), with (3,0)
+    // standing for (0,3) as its conjugate transpose (the host reads that block mirrored).  (Two code paths with their
+    // own pair lists made the compiler hold both sets of operands: 256 registers and 100 spilled.)
+    constexpr int P = T * (T + 1) / 2, NL = 4 * T /* loads per wave and tile */;
+    constexpr int MY_P = T == 4 ? 5 : P, MY_M = T == 4 ? 8 : 4;
+    constexpr int TILE_BYTES = 16 * T * 64 * 16, RED_BYTES = P * 2 * 256 * 8;
+    __shared__ __attribute__((aligned(16))) char smem[TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES];
+    amp_t *tile = reinterpret_cast<amp_t *>(smem);
+    double *red = reinterpret_cast<double *>(smem);
+    const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+    const uint32_t wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // this lane's place in a wave-load: row bits (kept bits < 6) and group bits (the other lane bits)
+    uint32_t r_low = 0, f_low = 0;
+    {
+        int rb = 0, fb = 0;
+        for (int b = 0; b < 6; ++b) {
+            if ((g.lmask >> b) & 1u) r_low |= ((lane >> b) & 1u) << rb++;
+            else f_low |= ((lane >> b) & 1u) << fb++;
+        }
+    }
+    // the NL loads of this wave: load j = NL wave + jj -> c_h = j mod 2^h, block bb = j >> h (s = bb >> l, b = bb mod 2^l).
+    // Everything about a load except the lane's own row / group bits is the same for the whole wave: scalar registers.
+    const uint32_t per_tile = 1u << (g.l + g.log_s);     // consecutive w values a tile consumes
+    auto lds_slot = [&](int jj) {                         // where my amplitude of load jj goes in the tile
+        const uint32_t j = NL * wave_s + jj, c_h = j & ((1u << g.h) - 1u), bb = j >> g.h;
+        const uint32_t sblk = bb >> g.l, b = bb & ((1u << g.l) - 1u);
+        const uint32_t row = (sblk << g.k) | (c_h << g.l) | r_low, slot = (b << (6 - g.l)) | f_low;
+        return row * 64 + (slot ^ (row & 15u));
+    };
+    auto fetch = [&](amp_t (&x)[NL], uint64_t t) {
+#pragma unroll
+        for (int jj = 0; jj < NL; ++jj) {
+            const uint32_t j = NL * wave_s + jj;
+            const uint64_t w = t * per_tile + (j >> g.h);
+            const uint64_t c_off = g.hoff[j & ((1u << g.h) - 1u)];    // scalar load
+            x[jj] = __builtin_nontemporal_load(a + deposit(w << 6, g) + c_off + lane);
+        }
+    };
+    f64x4 p1[MY_P], p2[MY_P], p3[MY_P];
+#pragma unroll
+    for (int p = 0; p < MY_P; ++p) p1[p] = p2[p] = p3[p] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const uint32_t shift = T == 4 ? (wave_s & 1u) : 0u;                       // row-tile rotation of this wave
+    const int m_first = MY_M * (T == 4 ? wave_s >> 1 : wave_s);
+    // operand slots of pair q (T = 4: the list A above; otherwise every pair ti <= tj in order)
+    constexpr int A_I[5] = {0, 2, 0, 2, 0}, A_J[5] = {0, 2, 1, 3, 2};
+    amp_t x[NL];
+    // tile order: with R regions, the workgroups in flight together read from R places of the register instead of one
+    // narrow window per kept-bit setting (kept bits on the top address bits: every stream would sit in the same channels)
+    const uint64_t per_region = g.regions > 1 ? g.tiles / g.regions : 0;
+    auto place = [&](uint64_t s) { return g.regions > 1 ? (s % g.regions) * per_region + s / g.regions : s; };
+    uint64_t t = blockIdx.x;
+    fetch(x, place(t));                                   // gridDim.x <= tiles: every workgroup owns at least one
+    for (; t < g.tiles; t += gridDim.x) {
+#pragma unroll
+        for (int jj = 0; jj < NL; ++jj) tile[lds_slot(jj)] = x[jj];
+        __syncthreads();
+        const uint64_t nxt = t + gridDim.x;
+        fetch(x, place(nxt < g.tiles ? nxt : blockIdx.x));   // unconditional (see k_rdm): past the end re-read and drop
+        auto step = [&](int mm) {
+            const int m = m_first + mm;
+            amp_t v[T];
+#pragma unroll
+            for (int tt = 0; tt < T; ++tt) v[tt] = tile[(16 * ((tt + shift) & (T - 1)) + i) * 64 + ((4 * m + kk) ^ i)];
+            if constexpr (T == 4) {
+#pragma unroll
+                for (int q = 0; q < MY_P; ++q) {
+                    const amp_t vi = v[A_I[q]], vj = v[A_J[q]];
+                    p1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(vi.x, vj.x, p1[q], 0, 0, 0);
+                    p2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(vi.y, vj.y, p2[q], 0, 0, 0);
+                    p3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(vi.x + vi.y, vj.x - vj.y, p3[q], 0, 0, 0);
+                }
+            } else {
+                int q = 0;
+#pragma unroll
+                for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                    for (int tj = ti; tj < T; ++tj, ++q) {
+                        p1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ti].x, v[tj].x, p1[q], 0, 0, 0);
+                        p2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ti].y, v[tj].y, p2[q], 0, 0, 0);
+                        p3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ti].x + v[ti].y, v[tj].x - v[tj].y, p3[q], 0, 0, 0);
+                    }
+            }
+            // the next step's LDS reads stay behind these MFMAs: hoisted, the operands of all steps are live at once
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (T == 4) {       // a real loop: unrolled, the eight steps of 15 MFMAs push the allocator into spills
+#pragma unroll 1
+            for (int mm = 0; mm < MY_M; ++mm) step(mm);
+        } else {
+#pragma unroll
+            for (int mm = 0; mm < MY_M; ++mm) step(mm);
+        }
+        __syncthreads();                                  // every wave is done with the tile before it is overwritten
+    }
+    // re = P1 + P2, im = P3 - P1 + P2; deterministic sum over the waves that share a pair, one partial per workgroup.
+    // Pair index p of slot pair q: T = 4, first half (0,0) (2,2) (0,1) (2,3) (0,2) = 0 7 1 8 2; second half (1,1) (3,3)
+    // (1,2) (3,0) (1,3) = 4 9 5 3 6, where 3 = (0,3) holds the block of (3,0): its conjugate transpose.
+    for (uint32_t wv = 0; wv < 4; ++wv) {
+        if (wave_s == wv) {
+            const bool first = T == 4 ? wv < 2 : wv == 0;
+#pragma unroll
+            for (int q = 0; q < MY_P; ++q) {
+                constexpr int HALF0[5] = {0, 7, 1, 8, 2}, HALF1[5] = {4, 9, 5, 3, 6};
+                const int p = T == 4 ? (shift ? HALF1[q] : HALF0[q]) : q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double *slot_re = red + ((p * 2 + 0) * 4 + r) * 64 + lane;
+                    double *slot_im = red + ((p * 2 + 1) * 4 + r) * 64 + lane;
+                    *slot_re = (first ? 0.0 : *slot_re) + (p1[q][r] + p2[q][r]);
+                    *slot_im = (first ? 0.0 : *slot_im) + (p3[q][r] - p1[q][r] + p2[q][r]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    double *out = partials + static_cast<size_t>(blockIdx.x) * (P * 2 * 256);
+    for (int e = threadIdx.x; e < P * 2 * 256; e += QSV_BLOCK) out[e] = red[e];
+}
+
 // out[e] = sum over blocks of partials[block][e].  16 entries x 16 slices per workgroup: slice s adds blocks s, s+16, ...
 // in order, the 16 slice sums are added in slice order through LDS -- a fixed summation tree, so the result does not
 // depend on scheduling (one thread per entry walking every block took 0.24 ms: a chain of ~1000 dependent-latency loads).
@@ -2417,7 +2567,7 @@ int qsvk_diag(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits
     if (rc) return rc;
     const double *dtable = reinterpret_cast<const double *>(staged.dev);
     const uint8_t *dpos = reinterpret_cast<const uint8_t *>(staged.dev + qsv_pad16(tbytes));
-    if (st->n >= RO_MIN_QUBITS && st->readout_variant == 0) {
+    if (st->n >= RO_MIN_QUBITS && st->readout_variant != 1) {
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_diag_table_s");
         hipLaunchKernelGGL(k_diag_table_s, dim3(static_cast<unsigned>(st->amps / (QSV_BLOCK * RO_ITEMS))), dim3(QSV_BLOCK), 0,
                            st->stream, st->data, st->amps, K, dpos, dtable);
@@ -2452,7 +2602,7 @@ int qsvk_phase(qsv_state *st, int nctrl, const int *cbits, double re, double im)
 }
 
 int qsvk_measure_probs(qsv_state *st, int bit, const double e0[4], const double e1[4], double *p0, double *p1) {
-    if (st->n >= RO_MIN_QUBITS && st->readout_variant == 0) {
+    if (st->n >= RO_MIN_QUBITS && st->readout_variant != 1) {
         const int grid = grid_for(st->amps >> (bit < QSV_LANE_BITS ? 0 : 1), QSV_BLOCK * RO_ITEMS, QSV_REDUCE_BLOCKS);
         const cplx a{e0[0], e0[1]}, b{e0[2], e0[3]}, c{e1[0], e1[1]}, d{e1[2], e1[3]};
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_measure_probs_s<%s>", bit < QSV_LANE_BITS ? "true" : "false");
@@ -2487,7 +2637,7 @@ int qsvk_collapse(qsv_state *st, int bit, const double e[4], double scale) {
     amp_t *fresh = nullptr;
     int rc = qsvk_scratch(st, pairs, &fresh);
     if (rc) return rc;
-    if (st->n >= RO_MIN_QUBITS && st->readout_variant == 0) {
+    if (st->n >= RO_MIN_QUBITS && st->readout_variant != 1) {
         const dim3 gd(static_cast<unsigned>(pairs / (QSV_BLOCK * RO_ITEMS))), bd(QSV_BLOCK);
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_collapse_s<%s>", bit < QSV_LANE_BITS ? "true" : "false");
         if (bit < QSV_LANE_BITS)
@@ -2515,7 +2665,7 @@ int qsvk_insert(qsv_state *st, int bit, const double amp[4]) {
     amp_t *fresh = nullptr;
     int rc = qsvk_scratch(st, out_amps, &fresh);
     if (rc) return rc;
-    if (st->n >= RO_MIN_QUBITS && st->readout_variant == 0) {
+    if (st->n >= RO_MIN_QUBITS && st->readout_variant != 1) {
         const dim3 gd(static_cast<unsigned>(st->amps / (QSV_BLOCK * RO_ITEMS))), bd(QSV_BLOCK);
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_insert_s<%s>", bit < QSV_LANE_BITS ? "true" : "false");
         if (bit < QSV_LANE_BITS)
@@ -2544,7 +2694,7 @@ int qsvk_permute(qsv_state *st, const int *src_bit_of_dst_bit) {
     amp_t *fresh = nullptr;
     int rc = qsvk_scratch(st, st->amps, &fresh);
     if (rc) return rc;
-    if (st->n >= RO_MIN_QUBITS && st->readout_variant == 0) {
+    if (st->n >= RO_MIN_QUBITS && st->readout_variant != 1) {
         // the tile: destination bits 0..2, the destinations of source bits 0..2, then the lowest other bits up to six
         PermTileArgs t;
         std::memset(&t, 0, sizeof(t));
@@ -2620,15 +2770,42 @@ int qsvk_reduced_density(qsv_state *st, int k, const int *bits, double *rho_out)
     g.D = D;
     for (int i = 0; i < k; ++i) g.pos[i] = static_cast<uint32_t>(sorted[i]);
     const int S = D < 16 ? 16 / D : 1;                   // groups sharing a 16-row tile (k_rdm)
-    const bool big = st->n >= RO_MIN_QUBITS && g.W % (4ull * S * 4 * (RDM_LOADS / T)) == 0;  // whole iterations for >= one workgroup
+    const bool old_form = st->readout_variant == 2;      // round 2's per-lane row loads (measurement variant)
+    const bool big = st->n >= RO_MIN_QUBITS && (old_form ? g.W % (4ull * S * 4 * (RDM_LOADS / T)) == 0   // whole iterations
+                                                         : g.W % (64ull * S) == 0 && g.W >= 64ull * S);   // whole tiles
+    RdmTileArgs gt;
+    std::memset(&gt, 0, sizeof(gt));
+    if (big && !old_form) {
+        gt.k = k;
+        for (int i = 0; i < k; ++i) {
+            if (sorted[i] < 6) {
+                gt.lmask |= 1u << sorted[i];
+                ++gt.l;
+            } else {
+                gt.pos[gt.h++] = static_cast<uint32_t>(sorted[i]);
+            }
+        }
+        gt.nins = gt.h;
+        gt.log_s = S == 1 ? 0 : S == 2 ? 1 : S == 4 ? 2 : 3;
+        gt.tiles = g.W / (64ull * S);
+        for (int c = 0; c < (1 << gt.h); ++c)
+            for (int j = 0; j < gt.h; ++j)
+                if ((c >> j) & 1) gt.hoff[c] |= 1ull << gt.pos[j];
+        // 8 regions where a kept bit sits on the high address bits (k <= 4 on bits 24..27: 1.14 -> 0.82 ms at n = 28) and
+        // for 64-row tiles; plain order otherwise (within 5 % either way: profiles/r03_rdm.txt)
+        const uint32_t want = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : ((sorted.back() >= 20 || k == 6) ? 8u : 0u);
+        gt.regions = want > 1 && gt.tiles % want == 0 ? want : 0;
+    }
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st->device);  // 256 if the query fails
     // a power-of-two grid, so that (waves in the grid) x RDM_U divides the (power-of-two) number of steps
     int blocks = 0;
-    if (big) {
+    if (big && old_form) {
         const uint64_t most = std::min<uint64_t>((T <= 2 ? 4ull : 2ull) * cus, std::max<uint64_t>(1, g.W / (4ull * S) / (4 * (RDM_LOADS / T))));
         blocks = 1;
         while (2ull * blocks <= most) blocks *= 2;
+    } else if (big) {   // persistent workgroups, as many as the LDS tiles (16 T KiB) and the accumulators let a CU hold
+        blocks = static_cast<int>(std::min<uint64_t>(gt.tiles, static_cast<uint64_t>(T == 4 ? 2 : T == 2 ? 4 : 8) * cus));
     }
     const int entries = big ? P * 2 * 256 : 2 * D * D;
     const size_t b_off = sizeof(uint64_t) * off.size(), b_out = sizeof(double) * entries,
@@ -2638,9 +2815,18 @@ int qsvk_reduced_density(qsv_state *st, int k, const int *bits, double *rho_out)
     char *p = reinterpret_cast<char *>(st->dev_matrix);
     uint64_t *d_off = reinterpret_cast<uint64_t *>(p);
     double *d_out = reinterpret_cast<double *>(p + b_off), *d_part = reinterpret_cast<double *>(p + b_off + b_out);
-    QSV_HIP(hipMemcpyAsync(d_off, off.data(), b_off, hipMemcpyHostToDevice, st->stream));
+    if (!(big && !old_form)) QSV_HIP(hipMemcpyAsync(d_off, off.data(), b_off, hipMemcpyHostToDevice, st->stream));
     std::vector<double> raw(entries);
-    if (big) {
+    if (big && !old_form) {
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_rdm_tile<%d>", T);
+        if (T == 1) hipLaunchKernelGGL(k_rdm_tile<1>, dim3(blocks), dim3(QSV_BLOCK), 0, st->stream, st->data, gt, d_part);
+        else if (T == 2) hipLaunchKernelGGL(k_rdm_tile<2>, dim3(blocks), dim3(QSV_BLOCK), 0, st->stream, st->data, gt, d_part);
+        else hipLaunchKernelGGL(k_rdm_tile<4>, dim3(blocks), dim3(QSV_BLOCK), 0, st->stream, st->data, gt, d_part);
+        rc = check_launch();
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_sum_partials, dim3((entries + 15) / 16), dim3(QSV_BLOCK), 0, st->stream, d_part,
+                           blocks, entries, d_out);
+    } else if (big) {
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_rdm<%d>", T);
         if (T == 1) hipLaunchKernelGGL(k_rdm<1>, dim3(blocks), dim3(QSV_BLOCK), 0, st->stream, st->data, g, d_off, d_part);
         else if (T == 2) hipLaunchKernelGGL(k_rdm<2>, dim3(blocks), dim3(QSV_BLOCK), 0, st->stream, st->data, g, d_off, d_part);
@@ -2676,15 +2862,18 @@ int qsvk_reduced_density(qsv_state *st, int k, const int *bits, double *rho_out)
                 const bool upper = r <= c;
                 const int rr = upper ? r : c, cc = upper ? c : r;
                 const int ti = rr / 16, tj = cc / 16;
+                // k_rdm_tile<4> holds pair (0, 3) as the block of (3, 0): read it mirrored, imaginary part negated
+                const bool mirrored = !old_form && T == 4 && ti == 0 && tj == 3;
                 int pidx = 0;
                 for (int a = 0; a < ti; ++a) pidx += T - a;
                 pidx += tj - ti;
                 vr = vi = 0.0;
                 for (int sgrp = 0; sgrp < S; ++sgrp) {   // 2^k < 16: the diagonal blocks of the shared tile add up
-                    const int row = rr % 16 + D * sgrp * (D < 16), col = cc % 16 + D * sgrp * (D < 16);
+                    int row = rr % 16 + D * sgrp * (D < 16), col = cc % 16 + D * sgrp * (D < 16);
+                    if (mirrored) std::swap(row, col);
                     const int reg = row / 4, lane = (row % 4) * 16 + col;
                     vr += raw[((pidx * 2 + 0) * 4 + reg) * 64 + lane];
-                    vi += raw[((pidx * 2 + 1) * 4 + reg) * 64 + lane];
+                    vi += (mirrored ? -1.0 : 1.0) * raw[((pidx * 2 + 1) * 4 + reg) * 64 + lane];
                 }
                 if (!upper) vi = -vi;  // rho[r][c] = conj(rho[c][r])
                 if (r == c) vi = 0.0;

@@ -449,22 +449,28 @@ def test_reduced_density_matrices_and_density_registers(golden):
             assert maxdiff(da.reduced_density(kept), want) < 1e-14, (tag, kept)
         assert da.last_kernel() == "k_rdm_small"
     # registers large enough for the matrix-core kernel: every k, kept qubits anywhere, in any order
+    # (round 3: the LDS-staged workgroup tile k_rdm_tile is the shipped form; variant 2 keeps round 2's k_rdm)
     rng = np.random.default_rng(8)
-    for n in (14, 16):
+    for n in (14, 16, 19):
         ket = W.random_ket(n, 80 + n)
         dev = DeviceState.from_numpy(ket)
-        for k in range(1, 7):
-            for trial in range(3):
-                kept = [int(q) for q in rng.choice(n, size=k, replace=False)]
-                if trial == 0:
-                    kept = list(range(n - k, n))                  # the lowest index bits: rows inside a cache line
-                elif trial == 1:
-                    kept = list(range(k))[::-1]                   # the top bits, reversed
-                got = dev.reduced_density(kept)
-                assert dev.last_kernel() == f"k_rdm<{1 if k <= 4 else 2 if k == 5 else 4}>"
-                assert maxdiff(got, O.reduced_density(ket, kept)) < 1e-14, (n, kept)
-                assert abs(np.trace(got).real - 1.0) < 1e-13 and maxdiff(got, got.conj().T) == 0.0
-        assert np.array_equal(dev.reduced_density([3, 1]), dev.reduced_density([3, 1]))      # deterministic sums
+        for variant, name in ((0, "k_rdm_tile"), (2, "k_rdm")):
+            dev.set_option(_lib.OPT_READOUT_VARIANT, variant)
+            for k in range(1, 7):
+                for trial in range(5):
+                    kept = [int(q) for q in rng.choice(n, size=k, replace=False)]
+                    if trial == 0:
+                        kept = list(range(n - k, n))                  # the lowest index bits: rows inside a cache line
+                    elif trial == 1:
+                        kept = list(range(k))[::-1]                   # the top bits, reversed
+                    elif trial == 2:
+                        kept = [n - 1 - b for b in sorted(rng.choice(np.arange(6, n), size=k, replace=False))]   # all from bit 6
+                    got = dev.reduced_density(kept)
+                    assert dev.last_kernel() == f"{name}<{1 if k <= 4 else 2 if k == 5 else 4}>", (variant, dev.last_kernel())
+                    assert maxdiff(got, O.reduced_density(ket, kept)) < 1e-14, (n, kept, variant)
+                    assert abs(np.trace(got).real - 1.0) < 1e-13 and maxdiff(got, got.conj().T) == 0.0
+            assert np.array_equal(dev.reduced_density([3, 1]), dev.reduced_density([3, 1]))      # deterministic sums
+        dev.set_option(_lib.OPT_READOUT_VARIANT, 0)
     with pytest.raises(ValueError):
         dev.reduced_density(list(range(7)))
     with pytest.raises(ValueError):
