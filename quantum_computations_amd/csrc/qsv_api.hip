@@ -329,25 +329,39 @@ int qsv_upload(qsv_state *st, const double *host, uint64_t offset, uint64_t coun
     return QSV_OK;
 }
 
-// Make the pages of [p, p + bytes) present and writable, with `threads` threads.  A freshly allocated destination
+// Make the pages of [p, p + bytes) present and writable, with up to `threads` threads.  A freshly allocated destination
 // (np.empty of 4 GiB is an untouched mmap) otherwise takes its one million page faults inside the copy, one after the
 // other: that, not PCIe, was the 16.8 GB/s of round 1's downloads.  Writing back the byte just read keeps the content.
-static void prefault(char *p, size_t bytes, int threads) {
+// Nothing here may leave through the C ABI as an exception: std::thread throws std::system_error when the process is at
+// its thread limit (the GPU runner enforces one), so every creation is guarded -- whatever threads did start are joined,
+// the range they did not cover is touched by the calling thread.  No madvise: the mapping belongs to the caller.
+static void prefault(char *p, size_t bytes, int threads) noexcept {
     const size_t page = 4096;
     char *first = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(p) + page - 1) / page * page);
     char *last = p + bytes;
     if (first >= last) return;
-    madvise(first, static_cast<size_t>(last - first) / page * page, MADV_HUGEPAGE);  // fewer, larger faults where allowed
-    std::vector<std::thread> pool;
     const size_t pages = static_cast<size_t>(last - first + page - 1) / page;
-    for (int t = 0; t < threads; ++t)
-        pool.emplace_back([=] {
-            for (size_t i = pages * t / threads; i < pages * (t + 1) / threads; ++i) {
-                volatile char *c = first + i * page;
-                *c = *c;
-            }
-        });
-    for (auto &th : pool) th.join();
+    auto touch = [first](size_t from, size_t to) {
+        constexpr size_t page = 4096;
+        for (size_t i = from; i < to; ++i) {
+            volatile char *c = first + i * page;
+            *c = *c;
+        }
+    };
+    std::thread pool[16];
+    threads = std::max(1, std::min(threads, 16));
+    int started = 0;
+    for (int t = 1; t < threads; ++t) {                  // slice 0 is the caller's own
+        try {
+            pool[started] = std::thread(touch, pages * t / threads, pages * (t + 1) / threads);
+            ++started;
+        } catch (...) {
+            touch(pages * t / threads, pages);               // no more threads: the rest is done here
+            break;
+        }
+    }
+    touch(0, pages / threads);
+    for (int t = 0; t < started; ++t) pool[t].join();
 }
 
 int qsv_download(qsv_state *st, double *host, uint64_t offset, uint64_t count) {
@@ -368,11 +382,18 @@ int qsv_download(qsv_state *st, double *host, uint64_t offset, uint64_t count) {
     for (size_t done = 0; done < bytes; done += piece) {
         const size_t len = std::min(piece, bytes - done);
         std::thread ahead;
-        if (done + len < bytes)
-            ahead = std::thread(prefault, dst + done + len, std::min(piece, bytes - done - len), threads);
+        bool ahead_running = false;
+        if (done + len < bytes) {
+            try {
+                ahead = std::thread(prefault, dst + done + len, std::min(piece, bytes - done - len), threads);
+                ahead_running = true;
+            } catch (...) {
+                // at the thread limit: the copy below takes the faults itself (slower, still correct)
+            }
+        }
         const hipError_t e = hipMemcpyAsync(dst + done, src + done, len, hipMemcpyDeviceToHost, st->stream);
         const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize(st->stream) : e;
-        if (ahead.joinable()) ahead.join();
+        if (ahead_running) ahead.join();
         if (e2 != hipSuccess) return qsv_fail(QSV_EHIP, std::string("download: ") + hipGetErrorString(e2));
     }
     return QSV_OK;

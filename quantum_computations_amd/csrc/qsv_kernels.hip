@@ -970,7 +970,24 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_fill_random(amp_t *__restrict__ a
 // bit below 6 is resolved inside the wave -- the partner amplitude comes from __shfl_xor, compaction / expansion by
 // one qubit is a lane gather -- so that every global access is a whole 1 KiB segment whatever the bit.
 // ----------------------------------------------------------------------------------------------------
-constexpr int RO_ITEMS = 4;
+constexpr int RO_ITEMS = 4;          // the reductions (k_measure_probs_s): four items per thread and trip
+// amplitudes per thread of the kernels that move the register (collapse, insert, permute, table diagonals): one -- the
+// plain copy kernel reaches 6.55 TB/s with one amplitude per thread and 6.05 with four (profiles/r03_copy_kernel.txt),
+// and these kernels follow it (profiles/r03_readout_kernels.csv).  QSV_RO_ITEMS = 1 / 2 / 4 for measurements.
+static int ro_move_items() {
+    static const int items = [] {
+        const char *e = getenv("QSV_RO_ITEMS");
+        const int v = e ? atoi(e) : 1;
+        return v == 2 || v == 4 ? v : 1;   // (the table diagonals take two: 6.2 TB/s against 5.85 with one or four)
+    }();
+    return items;
+}
+#define QSV_RO_DISPATCH(items, CALL)  \
+    do {                              \
+        if ((items) == 4) { constexpr int IT = 4; CALL; } \
+        else if ((items) == 2) { constexpr int IT = 2; CALL; } \
+        else { constexpr int IT = 1; CALL; } \
+    } while (0)
 constexpr int RO_MIN_QUBITS = 14;  // below this the plain grid-stride forms run (tiles of 2^10 amplitudes must divide)
 
 __device__ __forceinline__ amp_t shfl_amp(amp_t v, int src_lane) {
@@ -1034,21 +1051,21 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_measure_probs_s(const amp_t *__re
 }
 
 // out[w] = scale * (e0 a[i0] + e1 a[i0 + s]), i0 = w with a zero inserted at `bit`.
-template <bool LOW>
+template <bool LOW, int ITEMS>
 __global__ __launch_bounds__(QSV_BLOCK) void k_collapse_s(const amp_t *__restrict__ a, amp_t *__restrict__ out,
                                                           uint64_t pairs, int bit, cplx e0, cplx e1, double scale) {
     const cplx f0 = {e0.re * scale, e0.im * scale}, f1 = {e1.re * scale, e1.im * scale};
-    const uint64_t w0 = (blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + (threadIdx.x & ~63u)) * RO_ITEMS + (threadIdx.x & 63);
+    const uint64_t w0 = (blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + (threadIdx.x & ~63u)) * ITEMS + (threadIdx.x & 63);
     if constexpr (LOW) {
-        // a wave turns 2 * RO_ITEMS rows of 64 amplitudes into RO_ITEMS rows of 64 results: the pair sum lands in the
+        // a wave turns 2 * ITEMS rows of 64 amplitudes into ITEMS rows of 64 results: the pair sum lands in the
         // lanes whose bit is 0, and output lane l gathers it from lane insert_zero(l & 31, bit) of row l >> 5
         const int lane = threadIdx.x & 63;
         const int src = static_cast<int>(insert_zero(static_cast<uint64_t>(lane & 31), bit));
-        amp_t v[2 * RO_ITEMS];
+        amp_t v[2 * ITEMS];
 #pragma unroll
-        for (int u = 0; u < 2 * RO_ITEMS; ++u) v[u] = __builtin_nontemporal_load(a + 2 * (w0 - lane) + u * 64 + lane);
+        for (int u = 0; u < 2 * ITEMS; ++u) v[u] = __builtin_nontemporal_load(a + 2 * (w0 - lane) + u * 64 + lane);
 #pragma unroll
-        for (int u = 0; u < RO_ITEMS; ++u) {
+        for (int u = 0; u < ITEMS; ++u) {
             const amp_t ra = cfma(f1, shfl_xor_amp(v[2 * u], 1 << bit), cmul(f0, v[2 * u]));
             const amp_t rb = cfma(f1, shfl_xor_amp(v[2 * u + 1], 1 << bit), cmul(f0, v[2 * u + 1]));
             const amp_t ga = shfl_amp(ra, src), gb = shfl_amp(rb, src);
@@ -1056,27 +1073,27 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_collapse_s(const amp_t *__restric
         }
     } else {
         const uint64_t s = 1ull << bit;
-        amp_t lo[RO_ITEMS], hi[RO_ITEMS];
+        amp_t lo[ITEMS], hi[ITEMS];
 #pragma unroll
-        for (int u = 0; u < RO_ITEMS; ++u) {
+        for (int u = 0; u < ITEMS; ++u) {
             const uint64_t i = insert_zero(w0 + u * 64, bit);
             lo[u] = __builtin_nontemporal_load(a + i);
             hi[u] = __builtin_nontemporal_load(a + i + s);
         }
 #pragma unroll
-        for (int u = 0; u < RO_ITEMS; ++u)
+        for (int u = 0; u < ITEMS; ++u)
             __builtin_nontemporal_store(cfma(f1, hi[u], cmul(f0, lo[u])), out + w0 + u * 64);
     }
 }
 
 // out[j] = amp[bit(j)] * a[j with the bit removed]
-template <bool LOW>
+template <bool LOW, int ITEMS>
 __global__ __launch_bounds__(QSV_BLOCK) void k_insert_s(const amp_t *__restrict__ a, amp_t *__restrict__ out,
                                                         uint64_t in_amps, int bit, cplx c0, cplx c1) {
-    const uint64_t w0 = (blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + (threadIdx.x & ~63u)) * RO_ITEMS + (threadIdx.x & 63);
-    amp_t v[RO_ITEMS];
+    const uint64_t w0 = (blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) + (threadIdx.x & ~63u)) * ITEMS + (threadIdx.x & 63);
+    amp_t v[ITEMS];
 #pragma unroll
-    for (int u = 0; u < RO_ITEMS; ++u) v[u] = __builtin_nontemporal_load(a + w0 + u * 64);
+    for (int u = 0; u < ITEMS; ++u) v[u] = __builtin_nontemporal_load(a + w0 + u * 64);
     if constexpr (LOW) {
         // a row of 64 inputs becomes two rows of 64 outputs: output lane l of row h reads input lane 32 h + (l without
         // its `bit`) and takes the factor of its own bit
@@ -1084,7 +1101,7 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_insert_s(const amp_t *__restrict_
         const int from = static_cast<int>(((static_cast<uint32_t>(lane) >> (bit + 1)) << bit) | (lane & ((1 << bit) - 1)));
         const cplx c = ((lane >> bit) & 1) ? c1 : c0;
 #pragma unroll
-        for (int u = 0; u < RO_ITEMS; ++u) {
+        for (int u = 0; u < ITEMS; ++u) {
             const uint64_t o = 2 * (w0 - lane + u * 64) + lane;
             __builtin_nontemporal_store(cmul(c, shfl_amp(v[u], from)), out + o);
             __builtin_nontemporal_store(cmul(c, shfl_amp(v[u], 32 + from)), out + o + 64);
@@ -1092,7 +1109,7 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_insert_s(const amp_t *__restrict_
     } else {
         const uint64_t s = 1ull << bit;
 #pragma unroll
-        for (int u = 0; u < RO_ITEMS; ++u) {
+        for (int u = 0; u < ITEMS; ++u) {
             const uint64_t o = insert_zero(w0 + u * 64, bit);
             __builtin_nontemporal_store(cmul(c0, v[u]), out + o);
             __builtin_nontemporal_store(cmul(c1, v[u]), out + o + s);
@@ -1113,6 +1130,7 @@ struct PermTileArgs {
     uint8_t tile_src[6];     // source bit that feeds it
 };
 
+template <int ITEMS>
 __global__ __launch_bounds__(QSV_BLOCK) void k_permute_s(const amp_t *__restrict__ a, amp_t *__restrict__ out,
                                                          const PermTileArgs g,
                                                          const uint64_t *__restrict__ lut /*[bytes][256]*/) {
@@ -1127,11 +1145,11 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_permute_s(const amp_t *__restrict
     // wave-uniform on purpose (readfirstlane): the per-tile address arithmetic below then runs on the scalar unit
     const uint64_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (QSV_BLOCK / 64) + (threadIdx.x >> 6));
     const uint64_t waves = static_cast<uint64_t>(gridDim.x) * (QSV_BLOCK / 64);
-    for (uint64_t t0 = wave * RO_ITEMS; t0 < g.tiles; t0 += waves * RO_ITEMS) {
-        amp_t v[RO_ITEMS];
-        uint64_t dst[RO_ITEMS];
+    for (uint64_t t0 = wave * ITEMS; t0 < g.tiles; t0 += waves * ITEMS) {
+        amp_t v[ITEMS];
+        uint64_t dst[ITEMS];
 #pragma unroll
-        for (int u = 0; u < RO_ITEMS; ++u) {
+        for (int u = 0; u < ITEMS; ++u) {
             uint64_t d = t0 + u;
 #pragma unroll
             for (int k = 0; k < 6; ++k) d = insert_zero(d, g.tile_dst[k]);
@@ -1142,12 +1160,13 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_permute_s(const amp_t *__restrict
             if (t0 + u < g.tiles) v[u] = __builtin_nontemporal_load(a + (sidx | src_lane));
         }
 #pragma unroll
-        for (int u = 0; u < RO_ITEMS; ++u)
+        for (int u = 0; u < ITEMS; ++u)
             if (t0 + u < g.tiles) __builtin_nontemporal_store(v[u], out + dst[u]);
     }
 }
 
 // K-qubit diagonal (K <= 6): a[i] *= table[bits of i at bitpos], natural order, table in LDS.
+template <int ITEMS>
 __global__ __launch_bounds__(QSV_BLOCK) void k_diag_table_s(amp_t *__restrict__ a, uint64_t amps, int K,
                                                            const uint8_t *__restrict__ bitpos,
                                                            const double *__restrict__ table) {
@@ -1156,12 +1175,12 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_diag_table_s(amp_t *__restrict__ 
     if (threadIdx.x < (1 << K)) tab[threadIdx.x] = amp_t{table[2 * threadIdx.x], table[2 * threadIdx.x + 1]};
     if (threadIdx.x < K) bp[threadIdx.x] = bitpos[threadIdx.x];
     __syncthreads();
-    const uint64_t i0 = blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) * RO_ITEMS + threadIdx.x;
-    amp_t v[RO_ITEMS];
+    const uint64_t i0 = blockIdx.x * static_cast<uint64_t>(QSV_BLOCK) * ITEMS + threadIdx.x;
+    amp_t v[ITEMS];
 #pragma unroll
-    for (int u = 0; u < RO_ITEMS; ++u) v[u] = __builtin_nontemporal_load(a + i0 + u * QSV_BLOCK);
+    for (int u = 0; u < ITEMS; ++u) v[u] = __builtin_nontemporal_load(a + i0 + u * QSV_BLOCK);
 #pragma unroll
-    for (int u = 0; u < RO_ITEMS; ++u) {
+    for (int u = 0; u < ITEMS; ++u) {
         const uint64_t i = i0 + u * QSV_BLOCK;
         int sel = 0;
         for (int j = 0; j < K; ++j) sel |= static_cast<int>((i >> bp[j]) & 1ull) << (K - 1 - j);
@@ -1744,17 +1763,24 @@ int qsvk_stage(qsv_state *st, const void *a, size_t bytes_a, const void *b, size
         return QSV_OK;
     }
     if (!st->stage_dev) {
-        if (hipHostMalloc(reinterpret_cast<void **>(&st->stage_host), QSV_STAGE_SLOTS * QSV_STAGE_BYTES, 0) != hipSuccess) {
-            st->stage_host = nullptr;
-            return qsv_fail(QSV_ENOMEM, "pinned allocation of the gate-matrix staging ring failed");
+        // events first, then the buffers; stage_dev is published last, so a failure half way leaves the ring absent
+        // (not half built) and the next call starts over
+        hipEvent_t events[QSV_STAGE_SLOTS] = {};
+        for (int i = 0; i < QSV_STAGE_SLOTS; ++i)
+            if (hipEventCreate(&events[i]) != hipSuccess) {
+                for (int j = 0; j < i; ++j) (void)hipEventDestroy(events[j]);
+                return qsv_fail(QSV_EHIP, "event creation for the gate-matrix staging ring failed");
+            }
+        char *host = nullptr, *dev = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&host), QSV_STAGE_SLOTS * QSV_STAGE_BYTES, 0) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&dev), QSV_STAGE_SLOTS * QSV_STAGE_BYTES) != hipSuccess) {
+            if (host) (void)hipHostFree(host);
+            for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
+            return qsv_fail(QSV_ENOMEM, "allocation of the gate-matrix staging ring failed");
         }
-        if (hipMalloc(reinterpret_cast<void **>(&st->stage_dev), QSV_STAGE_SLOTS * QSV_STAGE_BYTES) != hipSuccess) {
-            (void)hipHostFree(st->stage_host);
-            st->stage_host = nullptr;
-            st->stage_dev = nullptr;
-            return qsv_fail(QSV_ENOMEM, "device allocation of the gate-matrix staging ring failed");
-        }
-        for (auto &ev : st->stage_done) QSV_HIP(hipEventCreate(&ev));
+        for (int i = 0; i < QSV_STAGE_SLOTS; ++i) st->stage_done[i] = events[i];
+        st->stage_host = host;
+        st->stage_dev = dev;
     }
     const int slot = static_cast<int>(st->stage_next++ % QSV_STAGE_SLOTS);
     if (st->stage_busy[slot]) {
@@ -1768,6 +1794,10 @@ int qsvk_stage(qsv_state *st, const void *a, size_t bytes_a, const void *b, size
     hipLaunchKernelGGL(k_stage_copy, dim3((n16 + QSV_BLOCK - 1) / QSV_BLOCK < 16 ? (n16 + QSV_BLOCK - 1) / QSV_BLOCK : 16), dim3(QSV_BLOCK), 0,
                        st->stream, reinterpret_cast<uint4 *>(dev), reinterpret_cast<const uint4 *>(host), n16);
     QSV_HIP(hipGetLastError());
+    // the slot is protected from here on: whatever the caller does next (its launch may fail, it may return early), the
+    // pinned slot is not rewritten before this copy kernel has read it.  qsvk_stage_done moves the mark behind the consumer.
+    QSV_HIP(hipEventRecord(st->stage_done[slot], st->stream));
+    st->stage_busy[slot] = true;
     out->dev = dev;
     out->slot = slot;
     return QSV_OK;
@@ -1775,7 +1805,7 @@ int qsvk_stage(qsv_state *st, const void *a, size_t bytes_a, const void *b, size
 
 int qsvk_stage_done(qsv_state *st, const StageRef &ref) {
     if (ref.slot < 0) return QSV_OK;
-    QSV_HIP(hipEventRecord(st->stage_done[ref.slot], st->stream));
+    QSV_HIP(hipEventRecord(st->stage_done[ref.slot], st->stream));   // re-record: now behind the kernel that reads the slot
     st->stage_busy[ref.slot] = true;
     return QSV_OK;
 }
@@ -2569,8 +2599,8 @@ int qsvk_diag(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits
     const uint8_t *dpos = reinterpret_cast<const uint8_t *>(staged.dev + qsv_pad16(tbytes));
     if (st->n >= RO_MIN_QUBITS && st->readout_variant != 1) {
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_diag_table_s");
-        hipLaunchKernelGGL(k_diag_table_s, dim3(static_cast<unsigned>(st->amps / (QSV_BLOCK * RO_ITEMS))), dim3(QSV_BLOCK), 0,
-                           st->stream, st->data, st->amps, K, dpos, dtable);
+        QSV_RO_DISPATCH(getenv("QSV_RO_ITEMS") ? ro_move_items() : 2, hipLaunchKernelGGL((k_diag_table_s<IT>), dim3(static_cast<unsigned>(st->amps / (QSV_BLOCK * IT))), dim3(QSV_BLOCK), 0,
+                           st->stream, st->data, st->amps, K, dpos, dtable));
     } else {
         const int grid = grid_for(st->amps, QSV_BLOCK, 4096);
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_diag_table");
@@ -2638,14 +2668,15 @@ int qsvk_collapse(qsv_state *st, int bit, const double e[4], double scale) {
     int rc = qsvk_scratch(st, pairs, &fresh);
     if (rc) return rc;
     if (st->n >= RO_MIN_QUBITS && st->readout_variant != 1) {
-        const dim3 gd(static_cast<unsigned>(pairs / (QSV_BLOCK * RO_ITEMS))), bd(QSV_BLOCK);
+        const int items = ro_move_items();
+        const dim3 gd(static_cast<unsigned>(pairs / (QSV_BLOCK * items))), bd(QSV_BLOCK);
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_collapse_s<%s>", bit < QSV_LANE_BITS ? "true" : "false");
         if (bit < QSV_LANE_BITS)
-            hipLaunchKernelGGL(k_collapse_s<true>, gd, bd, 0, st->stream, st->data, fresh, pairs, bit, cplx{e[0], e[1]},
-                               cplx{e[2], e[3]}, scale);
+            QSV_RO_DISPATCH(items, hipLaunchKernelGGL((k_collapse_s<true, IT>), gd, bd, 0, st->stream, st->data, fresh, pairs, bit,
+                                                      cplx{e[0], e[1]}, cplx{e[2], e[3]}, scale));
         else
-            hipLaunchKernelGGL(k_collapse_s<false>, gd, bd, 0, st->stream, st->data, fresh, pairs, bit, cplx{e[0], e[1]},
-                               cplx{e[2], e[3]}, scale);
+            QSV_RO_DISPATCH(items, hipLaunchKernelGGL((k_collapse_s<false, IT>), gd, bd, 0, st->stream, st->data, fresh, pairs, bit,
+                                                      cplx{e[0], e[1]}, cplx{e[2], e[3]}, scale));
     } else {
         const int grid = grid_for(pairs, QSV_BLOCK * 4, 8192);
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_collapse");
@@ -2666,14 +2697,15 @@ int qsvk_insert(qsv_state *st, int bit, const double amp[4]) {
     int rc = qsvk_scratch(st, out_amps, &fresh);
     if (rc) return rc;
     if (st->n >= RO_MIN_QUBITS && st->readout_variant != 1) {
-        const dim3 gd(static_cast<unsigned>(st->amps / (QSV_BLOCK * RO_ITEMS))), bd(QSV_BLOCK);
+        const int items = ro_move_items();
+        const dim3 gd(static_cast<unsigned>(st->amps / (QSV_BLOCK * items))), bd(QSV_BLOCK);
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_insert_s<%s>", bit < QSV_LANE_BITS ? "true" : "false");
         if (bit < QSV_LANE_BITS)
-            hipLaunchKernelGGL(k_insert_s<true>, gd, bd, 0, st->stream, st->data, fresh, st->amps, bit,
-                               cplx{amp[0], amp[1]}, cplx{amp[2], amp[3]});
+            QSV_RO_DISPATCH(items, hipLaunchKernelGGL((k_insert_s<true, IT>), gd, bd, 0, st->stream, st->data, fresh, st->amps, bit,
+                                                      cplx{amp[0], amp[1]}, cplx{amp[2], amp[3]}));
         else
-            hipLaunchKernelGGL(k_insert_s<false>, gd, bd, 0, st->stream, st->data, fresh, st->amps, bit,
-                               cplx{amp[0], amp[1]}, cplx{amp[2], amp[3]});
+            QSV_RO_DISPATCH(items, hipLaunchKernelGGL((k_insert_s<false, IT>), gd, bd, 0, st->stream, st->data, fresh, st->amps, bit,
+                                                      cplx{amp[0], amp[1]}, cplx{amp[2], amp[3]}));
     } else {
         const int grid = grid_for(out_amps, QSV_BLOCK * 4, 8192);
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_insert");
@@ -2720,10 +2752,11 @@ int qsvk_permute(qsv_state *st, const int *src_bit_of_dst_bit) {
         if (rc) return rc;
         QSV_HIP(hipMemcpyAsync(st->dev_matrix, lut.data(), sizeof(uint64_t) * lut.size(), hipMemcpyHostToDevice, st->stream));
         QSV_HIP(hipStreamSynchronize(st->stream));  // `lut` dies at return
-        const int grid = grid_for(t.tiles, (QSV_BLOCK / 64) * RO_ITEMS, 1 << 16);
+        const int items = ro_move_items();
+        const int grid = grid_for(t.tiles, (QSV_BLOCK / 64) * items, 1 << 22);
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_permute_s");
-        hipLaunchKernelGGL(k_permute_s, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, t,
-                           reinterpret_cast<const uint64_t *>(st->dev_matrix));
+        QSV_RO_DISPATCH(items, hipLaunchKernelGGL((k_permute_s<IT>), dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, fresh, t,
+                                                  reinterpret_cast<const uint64_t *>(st->dev_matrix)));
     } else {
         const int grid = grid_for(st->amps, QSV_BLOCK * 4, 8192);
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_permute");
@@ -2832,7 +2865,10 @@ int qsvk_reduced_density(qsv_state *st, int k, const int *bits, double *rho_out)
         else if (T == 2) hipLaunchKernelGGL(k_rdm<2>, dim3(blocks), dim3(QSV_BLOCK), 0, st->stream, st->data, g, d_off, d_part);
         else hipLaunchKernelGGL(k_rdm<4>, dim3(blocks), dim3(QSV_BLOCK), 0, st->stream, st->data, g, d_off, d_part);
         rc = check_launch();
-        if (rc) return rc;
+        if (rc) {
+            (void)hipStreamSynchronize(st->stream);   // the offsets' upload reads a local vector
+            return rc;
+        }
         hipLaunchKernelGGL(k_sum_partials, dim3((entries + 15) / 16), dim3(QSV_BLOCK), 0, st->stream, d_part,
                            blocks, entries, d_out);
     } else {
@@ -2841,7 +2877,10 @@ int qsvk_reduced_density(qsv_state *st, int k, const int *bits, double *rho_out)
                            d_off, d_out);
     }
     rc = check_launch();
-    if (rc) return rc;
+    if (rc) {
+        (void)hipStreamSynchronize(st->stream);
+        return rc;
+    }
     QSV_HIP(hipMemcpyAsync(raw.data(), d_out, b_out, hipMemcpyDeviceToHost, st->stream));
     QSV_HIP(hipStreamSynchronize(st->stream));
     // kernel order (row bit i <-> sorted[i]) -> caller order (bit k-1-j <-> bits[j])

@@ -302,13 +302,15 @@ __global__ __launch_bounds__(PLANE_THREADS) void k_mode2_plane(amp_t *__restrict
                                                                const double *__restrict__ coef,   // [threads][MAX_BLOCK]
                                                                const int32_t *__restrict__ rd0,   // [threads] first input
                                                                const int32_t *__restrict__ wr,    // [threads] my output
-                                                               const int32_t *__restrict__ wave_trip) {
+                                                               const int32_t *__restrict__ wave_trip,
+                                                               const int32_t *__restrict__ count) {  // [threads] my block's size
     __shared__ amp_t in_t[PLANE_THREADS];
     __shared__ amp_t out_t[PLANE_THREADS];
     const int tid = threadIdx.x;
     const bool active = static_cast<uint32_t>(tid) < g.batch_amps;
-    // lanes whose block is smaller than their wave's trip count multiply what they read past their block by 0.0:
-    // whatever that is must be finite (never-written tile slots would hold another kernel's leftovers)
+    // lanes whose block is smaller than their wave's trip count do not read past their block: input k0 + j >= my_n would
+    // lie outside the block -- up to 35 strides past it, i.e. outside in_t for the blocks near the end of the plane
+    const int my_n = count[tid];
     in_t[tid] = amp_t{0.0, 0.0};
     out_t[tid] = amp_t{0.0, 0.0};
     double c[MAX_BLOCK];
@@ -338,10 +340,10 @@ __global__ __launch_bounds__(PLANE_THREADS) void k_mode2_plane(amp_t *__restrict
         amp_t acc = {0.0, 0.0};
 #pragma unroll
         for (int k0 = 0; k0 < MAX_BLOCK; k0 += 4) {
-            if (k0 < nk) {  // wave-uniform; four LDS reads in flight per step (inputs past the trip count meet 0.0)
+            if (k0 < nk) {  // wave-uniform; four LDS reads in flight per step
                 amp_t x[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) x[j] = src[(k0 + j) * stride];
+                for (int j = 0; j < 4; ++j) x[j] = k0 + j < my_n ? src[(k0 + j) * stride] : amp_t{0.0, 0.0};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     acc.x = fma(c[k0 + j], x[j].x, acc.x);
@@ -621,7 +623,7 @@ static int launch_plane(qsv_state *st, uint64_t d, uint64_t L, int nblocks, cons
     const int used = per_batch * plane;
     // thread t: sorted position t / per_batch of plane slot t % per_batch, so that a wave holds elements of equal rank
     std::vector<double> coef(static_cast<size_t>(PLANE_THREADS) * MAX_BLOCK, 0.0);
-    std::vector<int32_t> rd0(PLANE_THREADS, 0), wr(PLANE_THREADS, 0), trip(PLANE_THREADS / 64, 0);
+    std::vector<int32_t> rd0(PLANE_THREADS, 0), wr(PLANE_THREADS, 0), trip(PLANE_THREADS / 64, 0), cnt(PLANE_THREADS, 0);
     for (int t = 0; t < used; ++t) {
         const Elem &el = elems[t / per_batch];
         const int slot = t % per_batch;
@@ -635,21 +637,23 @@ static int launch_plane(qsv_state *st, uint64_t d, uint64_t L, int nblocks, cons
             rd0[t] = slot * plane + static_cast<int>(off[idx_start[el.block]]);
         }
         trip[t / 64] = std::max(trip[t / 64], el.size);
+        cnt[t] = el.size;
     }
-    // one image [coef | rd0 | wr | trip] through the staging ring (no host wait: see qsvk_stage)
+    // one image [coef | rd0 | wr | trip | cnt] through the staging ring (no host wait: see qsvk_stage)
     const size_t b_c = qsv_pad16(sizeof(double) * coef.size()), b_i = qsv_pad16(sizeof(int32_t) * PLANE_THREADS);
-    std::vector<char> image(b_c + 3 * b_i, 0);
+    std::vector<char> image(b_c + 4 * b_i, 0);
     memcpy(image.data(), coef.data(), sizeof(double) * coef.size());
     memcpy(image.data() + b_c, rd0.data(), sizeof(int32_t) * PLANE_THREADS);
     memcpy(image.data() + b_c + b_i, wr.data(), sizeof(int32_t) * PLANE_THREADS);
     memcpy(image.data() + b_c + 2 * b_i, trip.data(), sizeof(int32_t) * trip.size());
+    memcpy(image.data() + b_c + 3 * b_i, cnt.data(), sizeof(int32_t) * PLANE_THREADS);
     StageRef staged;
     int rc = qsvk_stage(st, image.data(), image.size(), nullptr, 0, &staged);
     if (rc) return rc;
     char *p = staged.dev;
     double *d_c = reinterpret_cast<double *>(p);
     int32_t *d_r = reinterpret_cast<int32_t *>(p + b_c), *d_w = reinterpret_cast<int32_t *>(p + b_c + b_i),
-            *d_t = reinterpret_cast<int32_t *>(p + b_c + 2 * b_i);
+            *d_t = reinterpret_cast<int32_t *>(p + b_c + 2 * b_i), *d_n = reinterpret_cast<int32_t *>(p + b_c + 3 * b_i);
     PlaneArgs g;
     g.batches = L / per_batch;
     g.batch_amps = static_cast<uint32_t>(used);
@@ -661,7 +665,7 @@ static int launch_plane(qsv_state *st, uint64_t d, uint64_t L, int nblocks, cons
     const int cstride = (stride == 31 || stride == -31) ? static_cast<int>(stride) : 0;
     snprintf(st->last_kernel, sizeof(st->last_kernel), "k_mode2_plane<%d, %s>", cstride, nt ? "true" : "false");
 #define QSV_LAUNCH_PLANE(S, N) \
-    hipLaunchKernelGGL((k_mode2_plane<S, N>), dim3(grid), dim3(PLANE_THREADS), 0, st->stream, st->data, g, d_c, d_r, d_w, d_t)
+    hipLaunchKernelGGL((k_mode2_plane<S, N>), dim3(grid), dim3(PLANE_THREADS), 0, st->stream, st->data, g, d_c, d_r, d_w, d_t, d_n)
     if (cstride == 31) { if (nt) QSV_LAUNCH_PLANE(31, true); else QSV_LAUNCH_PLANE(31, false); }
     else if (cstride == -31) { if (nt) QSV_LAUNCH_PLANE(-31, true); else QSV_LAUNCH_PLANE(-31, false); }
     else { if (nt) QSV_LAUNCH_PLANE(0, true); else QSV_LAUNCH_PLANE(0, false); }

@@ -249,6 +249,68 @@ int main() {
         EXPECT(qsv_destroy(st) == QSV_OK);
         EXPECT(qsv_create_view(7, 0, mem.data(), 64, nullptr, &st) != QSV_OK);
     }
+    // ---- a view re-pointed at windows of caller-owned memory (the sharded register's slices inside an exchange) ---------
+    {
+        std::vector<double> mem(2 * 1024, 0.0);
+        EXPECT(qsv_create_view(8, 0, mem.data(), 1024, nullptr, &st) == QSV_OK);
+        for (int w = 0; w < 4; ++w) {
+            EXPECT(qsv_rebind_view(st, 8, mem.data() + 2 * 256 * w, 256) == QSV_OK);
+            EXPECT(qsv_apply_1q(st, 3, matrix(2).data()) == QSV_OK);
+            int nq = 0;
+            EXPECT(qsv_num_qubits(st, &nq) == QSV_OK && nq == 8);
+        }
+        EXPECT(qsv_rebind_view(st, 9, mem.data(), 256) == QSV_EINVAL);          // capacity below the register
+        EXPECT(qsv_rebind_view(st, 8, nullptr, 256) == QSV_EINVAL);
+        EXPECT(qsv_rebind_view(st, 8, reinterpret_cast<char *>(mem.data()) + 8, 256) == QSV_EINVAL);   // misaligned
+        EXPECT(qsv_destroy(st) == QSV_OK);
+        EXPECT(qsv_create(6, 0, &st) == QSV_OK);
+        EXPECT(qsv_rebind_view(st, 6, mem.data(), 64) == QSV_ESTATE);           // owns its memory
+        EXPECT(qsv_destroy(st) == QSV_OK);
+    }
+    // ---- whole circuits in one launch: argument checks and buffer handling of qsv_run_programs --------------------------
+    {
+        // two instances: H on qubit 0 of 2 qubits; a measurement of 1 qubit.  Hand-packed programs (csrc/qsv_circuit.hip).
+        auto header = [](uint64_t op, uint64_t k, uint64_t len, uint64_t b0) { return op | (k << 8) | (len << 12) | (b0 << 28); };
+        std::vector<uint64_t> prog;
+        prog.push_back(header(2, 1, 9, 1));
+        for (int e = 0; e < 8; ++e) prog.push_back(0);
+        prog.push_back(header(0, 0, 1, 0));
+        const uint64_t first_len = prog.size();
+        prog.push_back(header(3, 1, 11, 0));
+        for (int e = 0; e < 10; ++e) prog.push_back(0);
+        prog.push_back(header(0, 0, 1, 0));
+        const uint64_t prog_off[3] = {0, first_len, prog.size()};
+        const int n0[2] = {2, 1};
+        const uint64_t state_off[3] = {0, 4, 6}, out_off[3] = {0, 4, 5}, res_off[3] = {0, 0, 1};
+        std::vector<double> in(12, 0.0), out(10, 0.0), probs(2, 0.0);
+        int results[1] = {0};
+        EXPECT(qsv_run_programs(0, 2, 2, prog.data(), prog_off, n0, in.data(), state_off, out.data(), out_off, results,
+                                probs.data(), res_off) == QSV_OK);
+        EXPECT(qsv_run_programs(0, 2, 14, prog.data(), prog_off, n0, in.data(), state_off, out.data(), out_off, results,
+                                probs.data(), res_off) == QSV_EINVAL);         // beyond the executor's register size
+        EXPECT(qsv_run_programs(0, 2, 1, prog.data(), prog_off, n0, in.data(), state_off, out.data(), out_off, results,
+                                probs.data(), res_off) == QSV_EINVAL);         // an instance larger than max_qubits
+        EXPECT(qsv_run_programs(0, 2, 2, prog.data(), prog_off, n0, in.data(), state_off, out.data(), out_off, nullptr,
+                                probs.data(), res_off) == QSV_EINVAL);         // measurements but nowhere to put them
+        EXPECT(qsv_run_programs(0, 0, 2, prog.data(), prog_off, n0, in.data(), state_off, out.data(), out_off, results,
+                                probs.data(), res_off) == QSV_OK);
+        // a batch large enough to grow the staging pool twice
+        for (int count : {64, 4096}) {
+            std::vector<uint64_t> po(count + 1), so(count + 1), oo(count + 1), ro(count + 1, 0);
+            std::vector<uint64_t> many;
+            std::vector<int> nn(count, 2);
+            for (int i = 0; i < count; ++i) {
+                po[i] = many.size();
+                many.insert(many.end(), prog.begin(), prog.begin() + first_len);
+                so[i] = oo[i] = 4ull * i;
+            }
+            po[count] = many.size();
+            so[count] = oo[count] = 4ull * count;
+            std::vector<double> big_in(8 * count, 0.0), big_out(8 * count, 0.0);
+            EXPECT(qsv_run_programs(0, count, 2, many.data(), po.data(), nn.data(), big_in.data(), so.data(), big_out.data(),
+                                    oo.data(), results, probs.data(), ro.data()) == QSV_OK);
+        }
+    }
     std::printf("sanitized host driver: %lu kernel launches prepared, %d failed expectations\n", qsv_stub_launches, failures);
     return failures ? 1 : 0;
 }
