@@ -139,10 +139,15 @@ __global__ __launch_bounds__(256) void k_panel_gram(const amp_t *__restrict__ Y,
     }
 }
 
+// (1024 threads: the sum of the 64 partial Gram matrices is a chain of load batches per thread -- 16 entries x 2 batches
+// with 256 threads, 130 us per launch on average and 29 % of the GPU time of the GKP Grover experiment; four times the
+// threads quarter the chain, and the trailing updates of the factorisation shrink with it)
+constexpr int FACTOR_THREADS = 1024;
+
 // One workgroup: G = sum of the partials (+ shift), upper Cholesky factor R with G = R^H R, its inverse, and the running
 // product r_total = R * r_prev.  first_round != 0 applies the CholeskyQR3 shift; otherwise pivots at rounding level
 // mark absent directions: their column of R^-1 is zeroed (the panel column becomes zero).
-__global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ partials, int nblocks, int l,
+__global__ __launch_bounds__(FACTOR_THREADS) void k_panel_factor(const amp_t *__restrict__ partials, int nblocks, int l,
                                                      uint64_t rows, int first_round,
                                                      const amp_t *__restrict__ r_prev, amp_t *__restrict__ r_total,
                                                      amp_t *__restrict__ r_out, const int *__restrict__ skip,
@@ -154,20 +159,20 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
         return;
     }
     __shared__ amp_t G[LMAX * LMAX];
-    __shared__ double deviation[4];
+    __shared__ double deviation[FACTOR_THREADS / 64];
     __shared__ amp_t Stage[LMAX * LMAX];
     __shared__ double pivot_floor, shift;
     __shared__ int absent[LMAX];
     const int t = threadIdx.x, entries = l * l;
-    for (int e = t; e < entries; e += 256) {
+    for (int e = t; e < entries; e += FACTOR_THREADS) {
         amp_t s = {0.0, 0.0};
         int b = 0;
-        for (; b + 32 <= nblocks; b += 32) {        // 32 independent loads in flight, summed in block order
-            amp_t v[32];
+        for (; b + 16 <= nblocks; b += 16) {        // 16 independent loads in flight, summed in block order
+            amp_t v[16];
 #pragma unroll
-            for (int k = 0; k < 32; ++k) v[k] = partials[static_cast<size_t>(b + k) * entries + e];
+            for (int k = 0; k < 16; ++k) v[k] = partials[static_cast<size_t>(b + k) * entries + e];
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
+            for (int k = 0; k < 16; ++k) {
                 s.x += v[k].x;
                 s.y += v[k].y;
             }
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
     }
     if (settled) {
         double dev = first_round ? 1.0 : 0.0;      // the shifted round never settles anything
-        for (int e = t; e < entries; e += 256) {
+        for (int e = t; e < entries; e += FACTOR_THREADS) {
             const int i = e / l, k = e % l;
             if (k >= i) dev = fmax(dev, fmax(fabs(G[e].x - (i == k ? 1.0 : 0.0)), fabs(G[e].y)));
         }
@@ -201,8 +206,11 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
         if ((t & 63) == 0) deviation[t >> 6] = dev;
     }
     __syncthreads();
-    if (settled && t == 0)
-        *settled = fmax(fmax(deviation[0], deviation[1]), fmax(deviation[2], deviation[3])) < 1e-7;
+    if (settled && t == 0) {
+        double worst = 0.0;
+        for (int w = 0; w < FACTOR_THREADS / 64; ++w) worst = fmax(worst, deviation[w]);
+        *settled = worst < 1e-7;
+    }
     // Blocked right-looking Cholesky, G = R^H R with R upper, 8 columns per step: the 8 x 8 diagonal block is factored by
     // the first wave alone (a wavefront executes its LDS instructions in order: no workgroup barriers inside), then all
     // threads solve the block row and update the trailing matrix -- 3 barriers per 8 columns instead of 3 per column.
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
         }
         __syncthreads();
         // block row: R[jb + p][k] for k beyond the block, by forward substitution with the block's R^H
-        for (int k = jb + nb + t; k < l; k += 256) {
+        for (int k = jb + nb + t; k < l; k += FACTOR_THREADS) {
             amp_t x[NB];
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
         __syncthreads();
         // trailing update G[i][k] -= sum_p conj(R[jb + p][i]) * R[jb + p][k] for jb + nb <= i <= k
         const int first = jb + nb, width = l - first;
-        for (int e = t; e < width * width; e += 256) {
+        for (int e = t; e < width * width; e += FACTOR_THREADS) {
             const int i = first + e / width, k = first + e % width;
             if (k >= i) {
                 amp_t acc = G[i * l + k];
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
         }
     }
     __syncthreads();
-    for (int e = t; e < entries; e += 256) {
+    for (int e = t; e < entries; e += FACTOR_THREADS) {
         const int i = e / l, k = e % l;
         // the factor handed to k_panel_solve: upper triangle, diagonal 0 marks an absent direction
         r_out[e] = (k < i || absent[i]) ? amp_t{0.0, 0.0} : G[e];
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(256) void k_panel_factor(const amp_t *__restrict__ 
     }
     __syncthreads();
     if (r_total)
-        for (int e = t; e < entries; e += 256) r_total[e] = Stage[e];
+        for (int e = t; e < entries; e += FACTOR_THREADS) r_total[e] = Stage[e];
 }
 
 // Y <- Y R^-1 in place for the upper triangular R of k_panel_factor (row-major [i * l + j]): forward substitution per row,
@@ -1049,7 +1057,7 @@ int panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t 
         const int *skip = flags && round > 0 ? flags + round : nullptr;
         int *next = flags && round < 2 ? flags + round + 1 : nullptr;
         hipLaunchKernelGGL(k_panel_gram, dim3(gram_blocks), dim3(256), lds, stream, Y, n, l, partials, skip);
-        hipLaunchKernelGGL(k_panel_factor, dim3(1), dim3(256), 0, stream, partials, gram_blocks, l, n, round == 0,
+        hipLaunchKernelGGL(k_panel_factor, dim3(1), dim3(FACTOR_THREADS), 0, stream, partials, gram_blocks, l, n, round == 0,
                            round == 0 ? nullptr : r_total, r_total, r_factor, skip, next);
         hipLaunchKernelGGL(k_panel_solve, dim3(apply_blocks), dim3(256), lds + sizeof(amp_t) * l * l, stream, Y, n, l,
                            r_factor, skip);

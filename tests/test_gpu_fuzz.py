@@ -18,7 +18,7 @@ def test_random_operation_sequences_match_the_oracle(seed):
                           capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
     assert "fuzz ok: 80 rounds" in proc.stdout
-    assert "k_dense_lds<5" in proc.stdout and "k_rdm<" in proc.stdout and "k_permute_s" in proc.stdout
+    assert "k_dense_lds<5" in proc.stdout and "k_rdm_tile<" in proc.stdout and "k_permute_s" in proc.stdout
 
 
 @pytest.mark.gpu

@@ -34,7 +34,8 @@ def main():
         ket = W.random_ket(n, int(rng.integers(1 << 30)))
         dev = DeviceState.from_numpy(ket)
         dev.set_option(_lib.OPT_KQ_VARIANT, int(rng.choice([0, 0, 0, 1, 2, 3])))
-        dev.set_option(_lib.OPT_READOUT_VARIANT, int(rng.choice([0, 0, 1])))
+        dev.set_option(_lib.OPT_READOUT_VARIANT, int(rng.choice([0, 0, 1, 2])))
+        dev.set_option(_lib.OPT_COMPLEX_PRODUCT, int(rng.choice([0, 0, 3, 4])))
         dev.set_option(_lib.OPT_SPECIALIZE, int(rng.choice([1, 1, 0])))
         want = ket
         log = []
