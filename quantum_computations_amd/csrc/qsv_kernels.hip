@@ -974,6 +974,12 @@ constexpr int RO_ITEMS = 4;          // the reductions (k_measure_probs_s): four
 // amplitudes per thread of the kernels that move the register (collapse, insert, permute, table diagonals): one -- the
 // plain copy kernel reaches 6.55 TB/s with one amplitude per thread and 6.05 with four (profiles/r03_copy_kernel.txt),
 // and these kernels follow it (profiles/r03_readout_kernels.csv).  QSV_RO_ITEMS = 1 / 2 / 4 for measurements.
+// items for a launch over `count` amplitudes: an AQL dispatch counts work-items in 32 bits (2^24 - 1 workgroups of 256),
+// so registers beyond 2^32 amplitudes per launch take two or four per thread
+static int ro_fit_items(int items, uint64_t count) {
+    while (items < 4 && count / (static_cast<uint64_t>(QSV_BLOCK) * items) > 0x00ffffffull) items *= 2;
+    return items;
+}
 static int ro_move_items() {
     static const int items = [] {
         const char *e = getenv("QSV_RO_ITEMS");
@@ -2599,7 +2605,7 @@ int qsvk_diag(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits
     const uint8_t *dpos = reinterpret_cast<const uint8_t *>(staged.dev + qsv_pad16(tbytes));
     if (st->n >= RO_MIN_QUBITS && st->readout_variant != 1) {
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_diag_table_s");
-        QSV_RO_DISPATCH(getenv("QSV_RO_ITEMS") ? ro_move_items() : 2, hipLaunchKernelGGL((k_diag_table_s<IT>), dim3(static_cast<unsigned>(st->amps / (QSV_BLOCK * IT))), dim3(QSV_BLOCK), 0,
+        QSV_RO_DISPATCH(ro_fit_items(getenv("QSV_RO_ITEMS") ? ro_move_items() : 2, st->amps), hipLaunchKernelGGL((k_diag_table_s<IT>), dim3(static_cast<unsigned>(st->amps / (QSV_BLOCK * IT))), dim3(QSV_BLOCK), 0,
                            st->stream, st->data, st->amps, K, dpos, dtable));
     } else {
         const int grid = grid_for(st->amps, QSV_BLOCK, 4096);
@@ -2668,7 +2674,7 @@ int qsvk_collapse(qsv_state *st, int bit, const double e[4], double scale) {
     int rc = qsvk_scratch(st, pairs, &fresh);
     if (rc) return rc;
     if (st->n >= RO_MIN_QUBITS && st->readout_variant != 1) {
-        const int items = ro_move_items();
+        const int items = ro_fit_items(ro_move_items(), pairs);
         const dim3 gd(static_cast<unsigned>(pairs / (QSV_BLOCK * items))), bd(QSV_BLOCK);
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_collapse_s<%s>", bit < QSV_LANE_BITS ? "true" : "false");
         if (bit < QSV_LANE_BITS)
@@ -2697,7 +2703,7 @@ int qsvk_insert(qsv_state *st, int bit, const double amp[4]) {
     int rc = qsvk_scratch(st, out_amps, &fresh);
     if (rc) return rc;
     if (st->n >= RO_MIN_QUBITS && st->readout_variant != 1) {
-        const int items = ro_move_items();
+        const int items = ro_fit_items(ro_move_items(), st->amps);
         const dim3 gd(static_cast<unsigned>(st->amps / (QSV_BLOCK * items))), bd(QSV_BLOCK);
         snprintf(st->last_kernel, sizeof(st->last_kernel), "k_insert_s<%s>", bit < QSV_LANE_BITS ? "true" : "false");
         if (bit < QSV_LANE_BITS)

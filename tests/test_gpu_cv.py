@@ -223,10 +223,11 @@ def test_fock_path_cfg4_small():
 def test_fock_path_cfg4_at_cutoff_32(n_modes, plane_kernel):
     """BASELINE config 4 at its own cutoff d = 32 (3 and 4 of its 6 modes: 32 Ki / 1 Mi amplitudes), on a random
     register.  d = 32 makes the register a 5-bit-per-mode qubit register, so this runs the instantiations the
-    6-mode configuration launches: S through ``k_dense_big<5, KL>`` with KL = 5 (last mode: all target bits inside a
-    wavefront), KL = 1 (second to last: one lane bit) and KL = 0 (every other mode); the Fock beam splitter through the
-    block kernels of ``qsv_apply_mode2_blocks`` on the last pair (R = 1: the plane is contiguous), the pair before it
-    (R = 32) and earlier pairs (R >= 1024), with the legs in either order."""
+    6-mode configuration launches: the real S(r) through the workgroup-tile kernel ``k_dense_tile<5, 8, true, ...>`` (every
+    mode whose five bits start at bit 3 or higher) and through the line-granular kernel ``k_dense_lds<5, 3, ...>`` (last
+    mode: all target bits inside a wavefront); the Fock beam splitter through ``k_mode2_blocks<256>`` (interior pairs, R =
+    32 and 1024), and on the last pair (R = 1: the plane is contiguous) through ``k_mode2_plane`` / ``k_mode2_blocks<64>``,
+    with the legs in either order.  The assertions below name the kernels that must have run."""
     d = 32
     rng = np.random.default_rng(320 + n_modes)
     psi = rng.standard_normal((d,) * n_modes) + 1j * rng.standard_normal((d,) * n_modes)
