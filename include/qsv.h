@@ -58,7 +58,8 @@ enum {
                                 the measured best per case, 1 = wave-shuffle butterflies, 2 = no exchange (per-thread
                                 strided access), 3 = line-granular exchange (address arithmetic for bits 3..5, LDS for
                                 bits 0..2), 4 = workgroup tile staged through LDS (k = 3..5, every target bit >= 3; other
-                                placements as 0), 5 = f64 matrix cores for k = 5 (k = 3, 4 as 0).  Values 1 and 2 also keep
+                                placements as 0), 5 = f64 matrix cores for k = 5 (k = 3, 4 as 0), 6 = f64 matrix cores fed from the LDS
+                                tile, matrix in registers, complex k = 5 on bits >= 3 (other cases as 0).  Values 1 and 2 also keep
                                 1- and 2-qubit gates on the register kernels (k_dense) instead of the workgroup-tile
                                 form (k_dense_tile12).  Same results; for measurements */
     QSV_OPT_PLANE_KERNEL = 8, /* qsv_apply_mode2_blocks on the last two modes with real blocks: 1 (default) = one

@@ -280,7 +280,7 @@ int qsv_set_option(qsv_state *st, int option, int64_t value) {
             st->complex_product = static_cast<int>(value);
             return QSV_OK;
         case QSV_OPT_KQ_VARIANT:
-            if (value < 0 || value > 5) return qsv_fail(QSV_EINVAL, "k-qubit kernel variant must be 0 .. 5");
+            if (value < 0 || value > 6) return qsv_fail(QSV_EINVAL, "k-qubit kernel variant must be 0 .. 6");
             st->kq_variant = static_cast<int>(value);
             return QSV_OK;
         default: return qsv_fail(QSV_EINVAL, "unknown option");

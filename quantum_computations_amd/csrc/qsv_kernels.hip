@@ -1937,6 +1937,100 @@ __global__ __launch_bounds__((1 << K) / ROWS * 64) void k_dense_tile(amp_t *__re
     }
 }
 
+// Complex 5-qubit blocks: the LDS tile of k_dense_tile feeding the f64 MATRIX CORES (round 3).  The vector kernels spend
+// 4 x 32 FP64 FMAs per amplitude; rocprofv3's SQ counters put their vector pipe at 81 % busy over the whole launch, at a
+// clock that the FP64 load pulls down to ~1.65 GHz (a 1-qubit gate runs at 2.3): they are bound by arithmetic, and the
+// three-multiplication form does not help them because its third plane of matrix rows (24 KiB per gate) no longer fits
+// the scalar cache the rows stream through.  Here the matrix lives in REGISTERS for the whole launch -- lane (i, kk)
+// holds M[16 t + i][4 s + kk] of every (row tile t, slice s): 32 complex values + their sums, 96 registers -- as the A
+// operand of v_mfma_f64_16x16x4_f64, and a complex product is three MFMAs (S1 += Ar xr, S2 += Ai xi, S3 += (Ar + Ai)(xr +
+// xi)): 48 MFMAs per 16 groups instead of 4096 wave-FMAs.  The HBM side is k_dense_tile's: a workgroup owns 64 columns,
+// wave q brings input rows 8 q .. 8 q + 7 straight into the [32][64] LDS tile (1 KiB per wave-instruction), then takes
+// the 16 columns 16 q .. 16 q + 15 through the matrix cores (B operand: lane (j, kk) reads [4 s + kk][16 q + j]), puts
+// the results back into its own columns of the tile, and after a barrier stores rows 8 q .. again as whole 1 KiB runs.
+// Persistent workgroups (the matrix registers are loaded once).
+template <bool NT>
+__global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dense_mtile5(
+    amp_t *__restrict__ a, const BigArgs g, const double *__restrict__ mat /* [r][c] (re, im) */,
+    const uint64_t *__restrict__ off) {
+    constexpr int D = 32, ROWS = 8;
+    __shared__ amp_t tiles[2][D * 64];   // two tiles: the next one is on its way from HBM while this one is computed and stored
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double are[8][2], aim[8][2], asum[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const double *e = mat + 2 * ((16 * t + li) * D + 4 * s + lk);
+            are[s][t] = e[0];
+            aim[s][t] = e[1];
+            asum[s][t] = e[0] + e[1];
+        }
+    uint64_t o[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) o[i] = off[q * ROWS + i];
+    const uint64_t n_tiles = g.W / 64;
+    auto base_of = [&](uint64_t t0) {
+        const uint64_t tile_id = (g.regions > 1 && n_tiles % g.regions == 0) ? (t0 % g.regions) * (n_tiles / g.regions) + t0 / g.regions : t0;
+        return deposit(g.w0 + tile_id * 64 + lane, g);
+    };
+    auto fetch = [&](uint64_t base, amp_t *tile) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the builtin exists in the device pass only
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i)
+            __builtin_amdgcn_global_load_lds(a + base + o[i], tile + (q * ROWS + i) * 64, 16, 0, NT ? 2 : 0);
+#endif
+    };
+    // Barriers are raw s_barrier + counted waits: __syncthreads() carries a fence that drains the vector-memory counter, i.e.
+    // waits for the NEXT tile's loads (issued just before) and for this tile's stores.  The counter retires loads, stores and
+    // LDS-DMA in issue order, so at the top of an iteration "all but the 8 youngest" = the previous tile's 8 stores may stay
+    // in flight while this tile's 8 loads (older) are complete.
+    uint64_t t0 = blockIdx.x;
+    uint64_t base = base_of(t0);
+    fetch(base, tiles[0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int it = 0; t0 < n_tiles; t0 += gridDim.x, ++it) {
+        amp_t *tile = tiles[it & 1];
+        // this tile's loads have landed (every wave waits for its own, then the barrier), and nobody reads the other tile
+        // any more (the LDS reads of the previous store phase have returned)
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint64_t next = t0 + gridDim.x;
+        const uint64_t next_base = base_of(next < n_tiles ? next : blockIdx.x);   // past the end: re-read the first tile, unused
+        fetch(next_base, tiles[(it & 1) ^ 1]);
+        f64x4 s1[2], s2[2], s3[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) s1[t] = s2[t] = s3[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const amp_t x = tile[(4 * s + lk) * 64 + 16 * q + li];
+            const double xs = x.x + x.y;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                s1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[s][t], x.x, s1[t], 0, 0, 0);
+                s2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[s][t], x.y, s2[t], 0, 0, 0);
+                s3[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(asum[s][t], xs, s3[t], 0, 0, 0);
+            }
+        }
+        // this wave has read everything it needs from its 16 columns (the reads are MFMA operands above): results in place
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                tile[(16 * t + lk + 4 * r) * 64 + 16 * q + li] = amp_t{s1[t][r] - s2[t][r], s3[t][r] - s1[t][r] - s2[t][r]};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my results are in the tile; the next tile's loads stay in flight
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const amp_t v = tile[(q * ROWS + i) * 64 + lane];
+            if (NT) __builtin_nontemporal_store(v, a + base + o[i]);
+            else a[base + o[i]] = v;
+        }
+        base = next_base;
+    }
+}
+
 // 1- and 2-qubit gates in the same form: one wave per input row (2 / 4 waves per workgroup), the matrix and the row
 // offsets in the kernel arguments.  On the benchmark circuit's placements 4-8 % faster than the register form (k_dense):
 // 1.28-1.34 ms against 1.31-1.48 per 1-qubit gate at n = 28, 1.36 against 1.48 on average over all pairs of bits >= 6.
@@ -2165,6 +2259,11 @@ static int dispatch_lds(qsv_state *st, int KB, bool nt, bool realm, dim3 gd, con
     return check_launch();
 }
 
+static bool mtile_default() {
+    static const bool on = [] { const char *e = getenv("QSV_MTILE"); return e ? atoi(e) != 0 : false; }();
+    return on;
+}
+
 // k = 3..5 on any register with at least k qubits.  bits[j] = bit position of matrix leg j (leg 0 most significant).
 static int launch_dense_big(qsv_state *st, int k, const int *bits, const double *m_user) {
     const int D = 1 << k;
@@ -2185,7 +2284,10 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     // for 0.9 of the 1.4 ms the memory traffic takes; the tile form's extra LDS round trip then costs more than it hides.
     // A persistent form with two LDS tiles and the next tile's loads in flight during the arithmetic was measured too:
     // 1.86 ms -- two workgroups per CU leave the FMA chains exposed to the scalar-load and LDS latencies)
-    const bool use_tile = tile_ok && (st->kq_variant == 4 || (st->kq_variant == 0 && (k <= 4 || real_matrix)));
+    // complex 5-qubit blocks on bits >= 3: the tile-fed matrix-core kernel (k_dense_mtile5; QSV_OPT_KQ_VARIANT = 6 forces it)
+    const bool use_mtile = tile_ok && k == 5 && !real_matrix && st->complex_product != 4 &&
+                           (st->kq_variant == 6 || (st->kq_variant == 0 && mtile_default()));
+    const bool use_tile = use_mtile || (tile_ok && (st->kq_variant == 4 || (st->kq_variant == 0 && (k <= 4 || real_matrix))));
     const bool transposed = KL > 0 && static_cast<int>(standin.size()) == KL && st->kq_variant != 2 && !use_tile;
     if (!transposed) {  // all targets high, or a register too small to transpose: lanes = lowest free bits
         high.assign(bits, bits + k);
@@ -2231,7 +2333,7 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     // ms against 1.61-1.77 for k_dense_big<5, 0>, 1.80-1.99 against 1.66-1.73 for k_dense_lds with targets inside a line
     // (two waves per SIMD instead of three).  These kernels are not waiting for the FP64 pipe.  On the matrix cores (k = 6)
     // the same trick is worth 13 %: see launch_dense_mfma.
-    const bool m3 = k == 5 && !real_matrix && st->complex_product == 3 && (use_tile || use_lds || KL == 0);
+    const bool m3 = !use_mtile && k == 5 && !real_matrix && st->complex_product == 3 && (use_tile || use_lds || KL == 0);
     std::vector<double> m(realm ? static_cast<size_t>(D) * D : (m3 ? 3ull : 2ull) * D * D);
     std::vector<int> ui(D);
     for (int c = 0; c < D; ++c) ui[c] = user_index(c);
@@ -2259,7 +2361,7 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     ins.insert(ins.end(), standin.begin(), standin.end());
     std::sort(ins.begin(), ins.end());
     const uint64_t W = st->amps >> k;
-    if (use_tile) {  // matrix slice of wave q, input c: ROWS consecutive entries  [q][c][i] = m[q ROWS + i][c]
+    if (use_tile && !use_mtile) {  // matrix slice of wave q, input c: ROWS consecutive entries  [q][c][i] = m[q ROWS + i][c]
         const int rows = k == 5 ? 8 : k == 4 ? 4 : 2, per = realm ? 1 : m3 ? 3 : 2;
         std::vector<double> mt(m.size());
         for (int r = 0; r < D; ++r)
@@ -2274,6 +2376,24 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     if (rc) return rc;
     const double *dev_m = reinterpret_cast<const double *>(staged.dev);
     const uint64_t *dev_off = reinterpret_cast<const uint64_t *>(staged.dev + qsv_pad16(sizeof(double) * m.size()));
+    if (use_mtile) {
+        BigArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.W = W;
+        g.nins = static_cast<int>(ins.size());
+        for (size_t j = 0; j < ins.size(); ++j) g.pos[j] = static_cast<uint32_t>(ins[j]);
+        const bool nt = st->nontemporal != 0;
+        g.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : tile_regions(k, ins);
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_dense_mtile5<%s>", nt ? "true" : "false");
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st->device);  // 256 if the query fails
+        const unsigned grid = static_cast<unsigned>(std::min<uint64_t>(W / 64, 2ull * cus));
+        if (nt) hipLaunchKernelGGL(k_dense_mtile5<true>, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, dev_m, dev_off);
+        else hipLaunchKernelGGL(k_dense_mtile5<false>, dim3(grid), dim3(QSV_BLOCK), 0, st->stream, st->data, g, dev_m, dev_off);
+        const int rc2 = check_launch();
+        if (rc2) return rc2;
+        return qsvk_stage_done(st, staged);
+    }
     if (use_tile) {
         const int rows = k == 5 ? 8 : k == 4 ? 4 : 2;
         BigArgs g;

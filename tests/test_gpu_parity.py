@@ -305,7 +305,7 @@ def test_complex_blocks_in_three_and_four_multiplications(product):
     assert all(three.values()) if product == 3 else not any(three.values()), (three, seen)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("k", [3, 4, 5])
 def test_register_blocked_kq_every_low_target_set(k, variant):
     """k = 3..5 dense gates with EVERY set of target bits below 6 (all subsets of the six lane bits, up to k of them),
@@ -348,6 +348,8 @@ def test_register_blocked_kq_every_low_target_set(k, variant):
         assert any(name.startswith(f"k_dense_tile<{k}, ") for name in kernels), kernels
     elif variant == 5:
         assert all(name.startswith("k_dense_mfma<5, ") for name in kernels) == (k == 5), kernels
+    elif variant == 6:
+        assert any(name.startswith("k_dense_mtile5<") for name in kernels) == (k == 5), kernels
     else:
         assert kernels == {f"k_dense_big<{k}, 0, false>"} or kernels == {f"k_dense_big<{k}, 0, true>",
                                                                         f"k_dense_big<{k}, 0, false>"}, kernels

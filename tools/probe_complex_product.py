@@ -34,9 +34,9 @@ for k in (5, 6):
             "2 low (b0,b3)": [0, 3] + [7 + 4 * j for j in range(k - 2)], "3 low (b0,b1,b2)": [0, 1, 2] + [7 + 4 * j for j in range(k - 3)],
             "3 low (b3,b4,b5)": [3, 4, 5] + [7 + 4 * j for j in range(k - 3)], "5 low (b0..b4)": [0, 1, 2, 3, 4] + [9] * (k - 5),
             "scattered": sorted(rng.choice(np.arange(3, n), k, replace=False).tolist())}
-    variants = (0, 3, 5) if k == 5 else (0,)
+    variants = (0, 3, 6) if k == 5 else (0,)
     print(f"# k = {k}, n = {n}: ms (TB/s) per kernel form; each cell: 4 multiplications | 3 multiplications; then max |diff| on 32 sampled amplitudes")
-    print("# forms: 0 = shipped choice, 3 = k_dense_lds, 5 = k_dense_mfma<5>")
+    print("# forms: 0 = shipped choice, 3 = k_dense_lds, 6 = k_dense_mtile5 (tile-fed matrix cores; its cells are the same kernel twice)")
     for label, bits in sets.items():
         qs = [n - 1 - b for b in bits]
         cells, worst = [], 0.0
