@@ -173,3 +173,30 @@ def test_batch_falls_back_per_instance_when_the_executor_cannot_take_a_circuit()
     assert maxdiff(out[1][0], O.apply_gate(ket, big.matrix, [0, 1, 2, 3, 4])) < GATE_TOL
     with pytest.raises(ValueError):
         Simulator([G.H(3)]).run(np.ones(8) / np.sqrt(8))       # the gate-by-gate path raises the reference's error
+
+
+def test_registers_that_shrink_to_nothing_and_grow_back():
+    """M on the last qubit leaves the empty register [norm]; Insert grows it again (simulator.py:22: the empty register is
+    the one-element vector).  Also a measurement right at a 16 KiB program-chunk boundary and a control on the 64th result."""
+    a, b, results = run_both([G.H(0), G.MZ(0, result=1)], np.array([1.0, 0.0]))
+    assert results == [1] and a.shape == (1,) and maxdiff(a, b) < GATE_TOL and abs(abs(a[0]) - 1.0) < 1e-15
+    a, b, _ = run_both([G.MZ(0, result=0), G.Insert(0, State.PLUS), G.H(0)], np.array([0.6, 0.8]))
+    assert a.shape == (2,) and maxdiff(a, b) < GATE_TOL and maxdiff(a, [1.0, 0.0]) < 1e-15
+    # 62 two-qubit gates (33 words each) put the measurement op across the first chunk boundary: it must be padded over
+    circuit = [G.CX(0, 1)] * 62 + [G.MX(1, result=0), G.H(0)]
+    a, b, _ = run_both(circuit, W.random_ket(2, 5))
+    assert maxdiff(a, b) < GATE_TOL
+    # 64 measurements + insertions, a control on the last recordable result
+    circuit = []
+    for i in range(64):
+        circuit += [G.H(1), G.MZ(1, result=i % 2), G.Insert(1, State.ZERO)]
+    circuit += [ClassicalControl(G.X(0), [63], [62]), ClassicalControl(G.H(1), [62], [])]
+    a, b, results = run_both(circuit, W.random_ket(2, 6))
+    assert results == [i % 2 for i in range(64)] and maxdiff(a, b) < CIRCUIT_TOL
+    # a control on result 64 is beyond the executor's record: that circuit takes the gate-by-gate path, same answer
+    more = circuit[:-2] + [G.H(1), G.MZ(1, result=1), G.Insert(1, State.ZERO), ClassicalControl(G.X(0), [64], [])]
+    sim = Simulator(more)
+    out = sim.run(W.random_ket(2, 6))
+    assert not sim.single_launch_used and len(sim.results) == 65
+    assert maxdiff(out, Simulator(more, single_launch=False).run(W.random_ket(2, 6))) < CIRCUIT_TOL
+
