@@ -538,6 +538,7 @@ def main():
                 if local and c and not (c == last and dev.event_elapsed_ms(2 * i, 2 * i + 1) < 1e-3):
                     per_kernel.setdefault(c, []).append(dev.event_elapsed_ms(2 * i, 2 * i + 1))
                 last = c
+    if recorded_steps and per_kernel:       # (a rank whose every gate moved data has no purely local launch to report)
         # dominant kernel = the full-traffic dense instantiation with the most device time
         full = {k: v for k, v in per_kernel.items() if k.startswith(("k_dense<", "k_dense_tile12<"))} or per_kernel
         dominant = max(full, key=lambda k: sum(full[k]))
