@@ -62,6 +62,30 @@ def main():
     assert abs(p[0] - 0.5) < 1e-14 and abs(p[1] - 0.5) < 1e-14
     assert abs(st.norm2() - 1.0) < 1e-13
 
+    # 1b. the sharded register against the UNSHARDED one on the same GPU (round 3): the same counter-based initial state,
+    # the same 40-gate circuit through Simulator.run on both (the sharded run plans its exchanges, reorders commuting gates
+    # and lets low-bit gates ride inside the exchange steps); probabilities of 256 basis states and the reduced density
+    # matrix of one remote + one local qubit must agree.  Rank 0 holds the unsharded copy (n <= 31: 32 GiB).
+    if n <= 31:
+        from quantum_computations_amd.device import DeviceState
+        st.fill_random(11)
+        circuit = W.to_gates(W.random_circuit(n, 40, 17))
+        Simulator(circuit).run(st)
+        rng = np.random.default_rng(3)
+        probe = [int(v) for v in rng.integers(0, 1 << n, 256)]
+        got_p = st.probabilities(probe)
+        got_rho = st.reduced_density([0, n - 1])
+        if rank == 0:
+            ref = DeviceState.random(n, 11)
+            for gate in circuit:
+                gate.apply(ref)
+            want_p = ref.probabilities(probe)
+            want_rho = ref.reduced_density([0, n - 1])
+            ref.close()
+            assert float(np.max(np.abs(got_p - want_p))) < 1e-12 * float(np.max(want_p)) + 1e-24, "sharded vs unsharded probabilities"
+            assert float(np.max(np.abs(got_rho - want_rho))) < 1e-12, "sharded vs unsharded reduced density matrix"
+        dist.barrier()
+
     # 2. a random circuit and its inverse on a random register: back to the start
     st.fill_random(7)
     probe = [0, 1, top, top + 12345, (1 << n) - 1]
