@@ -118,7 +118,7 @@ def test_simulator_with_fusion_matches_reference(golden, fuse):
 
 
 @pytest.mark.gpu
-def test_fused_28_qubit_circuit_agrees_with_unfused():
+def test_fused_28_qubit_circuit_agrees_with_unfused_and_with_the_oracle_block_by_block():
     from quantum_computations_amd.device import DeviceState
     from quantum_computations_amd.dv_simulator.simulator import Simulator
     n = 28
@@ -132,6 +132,35 @@ def test_fused_28_qubit_circuit_agrees_with_unfused():
     assert abs(a.inner(b) - 1.0) < 1e-10
     probe = np.random.default_rng(1).integers(0, 1 << n, 128)
     assert np.max(np.abs(a.probabilities(probe) - b.probabilities(probe))) < 1e-18
+    # and against the ORACLE at full size, block by block (round 3; the two device paths above could share a mistake):
+    # every fused block's matrix is rebuilt from its source gates with oracle.dv_oracle.apply_gate, and after the block
+    # has run, sampled groups of the 4 GiB register must equal that matrix times the group's amplitudes before it
+    from oracle import dv_oracle as O
+    rng = np.random.default_rng(2)
+    c = DeviceState.random(n, 29)
+    for block in sim.launch_list:
+        qs = list(block.indices)
+        k = len(qs)
+        sources = getattr(block, "sources", [block])
+        m = np.identity(1 << k, dtype=complex)
+        for col in range(1 << k):
+            ket = m[:, col].copy()
+            for g in sources:
+                ket = O.apply_gate(ket, np.asarray(g.matrix, dtype=complex), [qs.index(q) for q in g.indices])
+            m[:, col] = ket
+        bits = [n - 1 - q for q in qs]
+        others = [bit for bit in range(n) if bit not in bits]
+        bases = []
+        for _ in range(3):
+            v = int(rng.integers(0, 1 << (n - k)))
+            bases.append(sum(((v >> j) & 1) << bit for j, bit in enumerate(others)))
+        members = [[base | sum(((col >> (k - 1 - leg)) & 1) << bits[leg] for leg in range(k)) for col in range(1 << k)]
+                   for base in bases]
+        before = [np.array([c.download(j, 1)[0] for j in group]) for group in members]
+        block.apply(c)
+        for group, x in zip(members, before):
+            after = np.array([c.download(j, 1)[0] for j in group])
+            assert np.max(np.abs(after - m @ x)) < 1e-15, (qs, c.last_kernel())
 
 
 @pytest.mark.gpu
