@@ -69,9 +69,13 @@ enum {
                                 grid-stride kernels (always used below 14 qubits), 2 = as 0 but reduced density matrices
                                 with round 2's per-lane row loads (k_rdm) instead of the LDS-staged workgroup tile
                                 (k_rdm_tile).  Same results; for measurements */
-    QSV_OPT_COMPLEX_PRODUCT = 10 /* complex 32 x 32 / 64 x 64 blocks (qsv_apply_kq, k = 5, 6): 0 (default) = three real
+    QSV_OPT_COMPLEX_PRODUCT = 10, /* complex 32 x 32 / 64 x 64 blocks (qsv_apply_kq, k = 5, 6): 0 (default) = three real
                                 multiplications per matrix entry (Ar xr, Ai xi, (Ar + Ai)(xr + xi)), 4 = four.  Equal
                                 to rounding (normwise); for measurements */
+    QSV_OPT_SEQUENCE_WORK = 11  /* qsv_apply_sequence: the largest gate sequence applied as a sequence, in multiply-adds
+                                per 32 amplitudes (256 per one-qubit gate, 512 per two-qubit gate; the dense block costs
+                                4096).  Longer sequences report handled = 0.  -1 (default) = $QSV_SEQUENCE_WORK or 0, 0 = never: the
+                                sequence form measured no faster than the dense block; kept for measurements */
 };
 
 typedef struct qsv_state qsv_state;
@@ -131,6 +135,18 @@ int qsv_apply_controlled_1q(qsv_state *st, int n_controls, const int *controls, 
 int qsv_apply_mcphase(qsv_state *st, int n_qubits, const int *qubits, double re, double im);
 /* Generic k-qubit matrix (2^k x 2^k), 1 <= k <= 6: Gate(indices, matrix).apply (gates.py:7-54). */
 int qsv_apply_kq(qsv_state *st, int k, const int *qubits, const double *m);
+/* A fused block given as the SEQUENCE of the gates it was made of instead of their product: the same state as
+ * qsv_apply_kq with the product matrix (to rounding), i.e. consecutive iterations of the reference's loop
+ * `for gate in circuit: state = gate.apply(state)` (dv_simulator/simulator.py:40-52) in ONE pass over the register.
+ * Gate g acts on the block's legs legs[2 g] (and legs[2 g + 1] if arity[g] == 2) -- positions in `qubits` -- with the
+ * 2 x 2 / 4 x 4 row-major complex matrix that follows the previous gate's in `matrices`.  A dense 5-qubit block is the one
+ * gate shape bound by arithmetic (4 x 1024 FMAs per amplitude group); its few source gates cost a fraction of that on the
+ * amplitudes the thread already holds -- but measured no faster (two waves per SIMD; profiles/r03_sequence_blocks.txt), so
+ * the form is OFF unless QSV_OPT_SEQUENCE_WORK / $QSV_SEQUENCE_WORK allow it.  *handled = 0: no sequence form for this block
+ * / register (switched off, over the work limit, k != 5, gates on more than two qubits, tiny registers) -- nothing was
+ * applied, call qsv_apply_kq with the product matrix. */
+int qsv_apply_sequence(qsv_state *st, int k, const int *qubits, int n_gates, const int *arity, const int *legs,
+                       const double *matrices, int *handled);
 /* Qubit-axis permutation of the ket: permute_tensor_product (numpy_quantum.py:227-240); the qubit
  * at position j moves to position new_ordering[j]. */
 int qsv_permute(qsv_state *st, const int *new_ordering);

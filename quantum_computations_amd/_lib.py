@@ -10,7 +10,7 @@ LIB_PATH = Path(os.environ.get("QSV_LIBRARY", PKG_DIR / "libqsv.so"))
 
 QSV_OK, QSV_EINVAL, QSV_ENOMEM, QSV_EHIP, QSV_ESTATE = 0, -1, -2, -3, -4
 OPT_SPECIALIZE, OPT_UNROLL, OPT_GRID_CAP, OPT_NONTEMPORAL, OPT_ITEM_STRIDE_BIT, OPT_TILE_REGIONS = 1, 2, 3, 4, 5, 6
-OPT_KQ_VARIANT, OPT_PLANE_KERNEL, OPT_READOUT_VARIANT, OPT_COMPLEX_PRODUCT = 7, 8, 9, 10
+OPT_KQ_VARIANT, OPT_PLANE_KERNEL, OPT_READOUT_VARIANT, OPT_COMPLEX_PRODUCT, OPT_SEQUENCE_WORK = 7, 8, 9, 10, 11
 
 _state_p = C.c_void_p
 _dbl_p = C.POINTER(C.c_double)
@@ -46,6 +46,7 @@ SIGNATURES: dict[str, list] = {
     "qsv_apply_controlled_1q": [_state_p, C.c_int, _int_p, C.c_int, C.c_void_p],
     "qsv_apply_mcphase": [_state_p, C.c_int, _int_p, C.c_double, C.c_double],
     "qsv_apply_kq": [_state_p, C.c_int, _int_p, C.c_void_p],
+    "qsv_apply_sequence": [_state_p, C.c_int, _int_p, C.c_int, _int_p, _int_p, C.c_void_p, _int_p],
     "qsv_permute": [_state_p, _int_p],
     "qsv_measure": [_state_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, _int_p, _dbl_p, _dbl_p],
     "qsv_measure_probs": [_state_p, C.c_int, C.c_void_p, C.c_void_p, _dbl_p, _dbl_p],

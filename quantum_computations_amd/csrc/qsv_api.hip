@@ -279,6 +279,10 @@ int qsv_set_option(qsv_state *st, int option, int64_t value) {
             if (value != 0 && value != 3 && value != 4) return qsv_fail(QSV_EINVAL, "complex product must be 0, 3 or 4");
             st->complex_product = static_cast<int>(value);
             return QSV_OK;
+        case QSV_OPT_SEQUENCE_WORK:
+            if (value < -1 || value > (1 << 20)) return qsv_fail(QSV_EINVAL, "sequence work limit out of range");
+            st->sequence_work = static_cast<int>(value);
+            return QSV_OK;
         case QSV_OPT_KQ_VARIANT:
             if (value < 0 || value > 6) return qsv_fail(QSV_EINVAL, "k-qubit kernel variant must be 0 .. 6");
             st->kq_variant = static_cast<int>(value);
@@ -581,9 +585,30 @@ int qsv_apply_kq(qsv_state *st, int k, const int *qubits, const double *m) {
         }
         return qsvk_diag(st, k, bits.data(), 0, nullptr, d.data());
     }
-    rc = qsvk_generic(st, k, bits.data(), m);
+    // no host wait: the matrix has been copied into the staging ring (qsvk_stage) before this returns -- a drain of the
+    // stream here (a leftover of round 1's synchronous upload, removed in round 3) left the GPU idle between the fused
+    // blocks of a circuit while the host prepared the next one
+    return qsvk_generic(st, k, bits.data(), m);
+}
+
+int qsv_apply_sequence(qsv_state *st, int k, const int *qubits, int n_gates, const int *arity, const int *legs,
+                       const double *matrices, int *handled) {
+    if (!valid(st) || !qubits || !arity || !legs || !matrices || !handled) return qsv_fail(QSV_EINVAL, "null pointer");
+    *handled = 0;
+    if (k < 1 || k > QSV_MAX_K) return qsv_fail(QSV_EINVAL, "k must be in 1..6");
+    int rc = check_qubits(st, k, qubits);
     if (rc) return rc;
-    QSV_HIP(hipStreamSynchronize(st->stream));  // the matrix upload read the caller's buffer
+    if (n_gates < 1) return qsv_fail(QSV_EINVAL, "a gate sequence needs at least one gate");
+    for (int g = 0; g < n_gates; ++g)
+        if (arity[g] < 1 || arity[g] > k) return qsv_fail(QSV_EINVAL, "gate sequence: arity outside 1..k");
+    if (k != 5 || st->n < QSV_LANE_BITS) return QSV_OK;       // only 5-qubit blocks have a sequence form (handled = 0)
+    QSV_HIP(hipSetDevice(st->device));
+    int bits[QSV_MAX_K];
+    for (int j = 0; j < k; ++j) bits[j] = bit_of(st, qubits[j]);
+    rc = qsvk_sequence5(st, bits, n_gates, arity, legs, matrices);
+    if (rc == QSV_UNHANDLED_KQ) return QSV_OK;
+    if (rc) return rc;
+    *handled = 1;
     return QSV_OK;
 }
 

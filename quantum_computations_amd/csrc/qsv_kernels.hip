@@ -508,6 +508,153 @@ __global__ __launch_bounds__(BLOCK) void k_dense_lds(amp_t *__restrict__ a, cons
 
 
 // ----------------------------------------------------------------------------------------------------
+// Fused 5-qubit blocks as a SEQUENCE of their source gates (round 3).  A dense 32 x 32 complex block costs 4 x 1024 real
+// FMAs per amplitude group -- the one shape of the gate path that is bound by arithmetic (the vector pipe is 81 % busy at
+// the clock its power draw leaves it: profiles/r03_k5_sq_counters.txt).  But a fused block IS a product of a few 1- and
+// 2-qubit gates (5.9 on average on the benchmark circuit): applied one after the other to the 32 amplitudes a thread
+// already holds in registers they cost 256 FMAs per 1-qubit gate and 512 per 2-qubit gate, ~2 400 per block instead of
+// 4 096, and nothing but the gates' own small matrices comes through the scalar cache.  Loads, the exchange of low target bits
+// (address arithmetic for lane bits 3..5, the XOR-swizzled LDS rows for bits 0..2) and stores are k_dense_big's /
+// k_dense_lds's; only the arithmetic in the middle differs.  The register index is runtime data of the gate list, the
+// register ARRAY must be indexed statically: one unrolled body per register bit (1-qubit gates) and per pair of register
+// bits (2-qubit gates, leg 0 canonicalised onto the higher bit by the host), selected by a wave-uniform switch.
+// ----------------------------------------------------------------------------------------------------
+struct SeqGate {
+    int32_t code;      // 0..4: 1-qubit gate on register bit `code`; 5 + p: 2-qubit gate on the p-th pair (hi, lo), hi > lo
+    int32_t pad[3];
+    double m[32];      // 2 x 2 or 4 x 4 row-major complex; 2-qubit: matrix index bit 1 <-> register bit hi
+};
+constexpr int SEQ_MAX_GATES = 48;
+static int seq_max_work() {
+    static const int v = [] {
+        const char *e = getenv("QSV_SEQUENCE_WORK");
+        return e ? atoi(e) : 0;      // measured (profiles/r03_sequence_blocks.txt): no faster than the dense block
+    }();
+    return v;
+}
+
+template <int J>
+__device__ __forceinline__ void seq_apply1(amp_t (&x)[32], const double *__restrict__ m) {
+    const cplx m00{m[0], m[1]}, m01{m[2], m[3]}, m10{m[4], m[5]}, m11{m[6], m[7]};
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        if (c & (1 << J)) continue;
+        const amp_t a0 = x[c], a1 = x[c | (1 << J)];
+        x[c] = cfma(m01, a1, cmul(m00, a0));
+        x[c | (1 << J)] = cfma(m11, a1, cmul(m10, a0));
+    }
+}
+
+template <int HI, int LO>
+__device__ __forceinline__ void seq_apply2(amp_t (&x)[32], const double *__restrict__ m) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        if (c & ((1 << HI) | (1 << LO))) continue;
+        const amp_t in[4] = {x[c], x[c | (1 << LO)], x[c | (1 << HI)], x[c | (1 << HI) | (1 << LO)]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            amp_t acc = cmul(cplx{m[8 * r], m[8 * r + 1]}, in[0]);
+#pragma unroll
+            for (int cc = 1; cc < 4; ++cc) acc = cfma(cplx{m[8 * r + 2 * cc], m[8 * r + 2 * cc + 1]}, in[cc], acc);
+            x[c | ((r >> 1) << HI) | ((r & 1) << LO)] = acc;
+        }
+    }
+}
+
+__device__ __forceinline__ void seq_run(amp_t (&x)[32], const SeqGate *__restrict__ gates, int n_gates) {
+#pragma unroll 1
+    for (int g = 0; g < n_gates; ++g) {
+        const double *m = gates[g].m;
+        switch (gates[g].code) {     // wave-uniform (scalar loads)
+            case 0: seq_apply1<0>(x, m); break;
+            case 1: seq_apply1<1>(x, m); break;
+            case 2: seq_apply1<2>(x, m); break;
+            case 3: seq_apply1<3>(x, m); break;
+            case 4: seq_apply1<4>(x, m); break;
+            case 5: seq_apply2<1, 0>(x, m); break;
+            case 6: seq_apply2<2, 0>(x, m); break;
+            case 7: seq_apply2<2, 1>(x, m); break;
+            case 8: seq_apply2<3, 0>(x, m); break;
+            case 9: seq_apply2<3, 1>(x, m); break;
+            case 10: seq_apply2<3, 2>(x, m); break;
+            case 11: seq_apply2<4, 0>(x, m); break;
+            case 12: seq_apply2<4, 1>(x, m); break;
+            case 13: seq_apply2<4, 2>(x, m); break;
+            default: seq_apply2<4, 3>(x, m); break;
+        }
+    }
+}
+
+// every target on bit 6 or higher: k_dense_big<5, 0>'s loads and in-place stores around the gate sequence
+template <bool NT>
+__global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_seq_big(amp_t *__restrict__ a, const BigArgs g, const SeqGate *__restrict__ gates,
+                                                      int n_gates, const uint64_t *__restrict__ hoff) {
+    constexpr int D = 32;
+    const uint64_t tile = (g.regions > 1 && gridDim.x % g.regions == 0)
+                              ? (blockIdx.x % g.regions) * (gridDim.x / g.regions) + blockIdx.x / g.regions
+                              : blockIdx.x;
+    const uint64_t w = g.w0 + tile * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x;
+    if (w >= g.W) return;
+    const uint64_t base = deposit(w, g);
+    amp_t x[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[c] = ld<NT>(a + base + hoff[c]);
+    seq_run(x, gates, n_gates);
+#pragma unroll
+    for (int c = 0; c < D; ++c) st<NT>(a + base + hoff[c], x[c]);
+}
+
+// targets below bit 6: k_dense_lds<5, KB>'s addressing and LDS exchange around the gate sequence
+template <int KB, bool NT>
+__global__ __launch_bounds__(QSV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_seq_lds(amp_t *__restrict__ a, const LdsArgs g, const SeqGate *__restrict__ gates,
+                                                      int n_gates, const uint64_t *__restrict__ hoff) {
+    constexpr int D = 32, NB = 1 << KB;
+    __shared__ amp_t tiles[KB > 0 ? NB * QSV_BLOCK : 1];
+    amp_t *tile = tiles + (KB > 0 ? NB * 64 * (threadIdx.x >> 6) : 0);
+    const uint64_t tile_id = (g.regions > 1 && gridDim.x % g.regions == 0)
+                                 ? (blockIdx.x % g.regions) * (gridDim.x / g.regions) + blockIdx.x / g.regions
+                                 : blockIdx.x;
+    const uint64_t w = g.w0 + tile_id * static_cast<uint64_t>(QSV_BLOCK) + threadIdx.x;
+    if (w >= g.W) return;  // W and w0 are multiples of 64: whole waves leave together
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t base = deposit(w, g) & ~static_cast<uint64_t>(g.amask);
+    for (int j = 0; j < g.na; ++j) base |= static_cast<uint64_t>((lane >> g.abit[j]) & 1u) << g.aE[j];
+    amp_t x[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[c] = ld<NT>(a + base + hoff[c]);
+    uint32_t my_row = 0;
+    if constexpr (KB > 0) {
+#pragma unroll
+        for (int v = 1; v < NB; ++v)
+            if ((lane & g.bmask) == g.bdep[v]) my_row = v;
+#pragma unroll
+        for (int o = 0; o < D / NB; ++o) {
+            wave_sync();
+#pragma unroll
+            for (int s = 0; s < NB; ++s) tile[s * 64 + (lane ^ g.bdep[s])] = x[o * NB + s];
+            wave_sync();
+#pragma unroll
+            for (int t = 0; t < NB; ++t) x[o * NB + t] = tile[my_row * 64 + (lane ^ g.bdep[t])];
+        }
+    }
+    seq_run(x, gates, n_gates);
+    if constexpr (KB > 0) {
+#pragma unroll
+        for (int o = 0; o < D / NB; ++o) {
+            wave_sync();
+#pragma unroll
+            for (int t = 0; t < NB; ++t) tile[my_row * 64 + (lane ^ g.bdep[t])] = x[o * NB + t];
+            wave_sync();
+#pragma unroll
+            for (int s = 0; s < NB; ++s) st<NT>(a + base + hoff[o * NB + s], tile[s * 64 + (lane ^ g.bdep[s])]);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < D; ++c) st<NT>(a + base + hoff[c], x[c]);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
 // 6-qubit dense gates.  2^6 complex FMAs per amplitude are 16 flop/B: above the fp64 ridge of the chip (~10 flop/B),
 // so this one kernel of the gate path is bounded by arithmetic, not by HBM, and a 64 x 64 matrix times a (64 x groups)
 // panel is a GEMM: it runs on the f64 matrix cores (v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4],
@@ -2472,6 +2619,141 @@ static int launch_dense_big(qsv_state *st, int k, const int *bits, const double 
     return qsvk_stage_done(st, staged);
 }
 
+
+// A fused 5-qubit block as the sequence of its source gates (k_seq_big / k_seq_lds).  bits[j] = bit position of block leg j;
+// gate g acts on block legs legs[2 g] (and legs[2 g + 1] when arity[g] == 2), its matrix follows the previous gate's in
+// `mats` (8 or 32 doubles).  QSV_UNHANDLED_KQ: the register or the sequence does not fit this form (the caller applies
+// the block's product matrix instead).
+int qsvk_sequence5(qsv_state *st, const int *bits, int n_gates, const int *arity, const int *legs, const double *mats) {
+    const int k = 5, D = 32;
+    if (n_gates < 1 || n_gates > SEQ_MAX_GATES || st->n < k) return QSV_UNHANDLED_KQ;
+    // multiply-adds per 32 amplitudes: 256 per one-qubit gate, 512 per two-qubit gate, 4096 for the dense block
+    int work = 0;
+    for (int gi = 0; gi < n_gates; ++gi) work += arity[gi] == 1 ? 256 : 512;
+    if (work > (st->sequence_work >= 0 ? st->sequence_work : seq_max_work())) return QSV_UNHANDLED_KQ;
+    const uint64_t W = st->amps >> k;
+    if (W < 64 || W % 64) return QSV_UNHANDLED_KQ;
+    std::vector<int> high, low;
+    for (int j = 0; j < k; ++j) (bits[j] >= QSV_LANE_BITS ? high : low).push_back(bits[j]);
+    std::sort(low.begin(), low.end());
+    const int KL = static_cast<int>(low.size());
+    std::vector<int> standin;
+    for (int b = QSV_LANE_BITS; b < st->n && static_cast<int>(standin.size()) < KL; ++b)
+        if (std::find(high.begin(), high.end(), b) == high.end()) standin.push_back(b);
+    if (static_cast<int>(standin.size()) != KL) return QSV_UNHANDLED_KQ;
+    const int KH = k - KL;
+    int KB = 0;
+    for (int b : low) KB += b < 3;
+    // register index c = (h << KL) | t: h bit i <-> high[i], t bit j <-> low[j] (as launch_dense_big)
+    std::vector<uint64_t> off(D, 0);
+    for (int c = 0; c < D; ++c) {
+        for (int i = 0; i < KH; ++i)
+            if ((c >> (KL + i)) & 1) off[c] |= 1ull << high[i];
+        for (int j = 0; j < KL; ++j)
+            if ((c >> j) & 1) off[c] |= 1ull << (low[j] >= 3 ? low[j] : standin[j]);
+    }
+    auto reg_bit = [&](int phys) {
+        for (int j = 0; j < KL; ++j)
+            if (low[j] == phys) return j;
+        for (int i = 0; i < KH; ++i)
+            if (high[i] == phys) return KL + i;
+        return -1;
+    };
+    std::vector<SeqGate> rec(n_gates);
+    const double *m = mats;
+    for (int gi = 0; gi < n_gates; ++gi) {
+        SeqGate &r = rec[gi];
+        std::memset(&r, 0, sizeof(r));
+        if (arity[gi] == 1) {
+            const int leg = legs[2 * gi];
+            if (leg < 0 || leg >= k) return qsv_fail(QSV_EINVAL, "gate sequence: leg outside the block");
+            r.code = reg_bit(bits[leg]);
+            std::memcpy(r.m, m, sizeof(double) * 8);
+            m += 8;
+        } else if (arity[gi] == 2) {
+            const int l0 = legs[2 * gi], l1 = legs[2 * gi + 1];
+            if (l0 < 0 || l0 >= k || l1 < 0 || l1 >= k || l0 == l1) return qsv_fail(QSV_EINVAL, "gate sequence: legs outside the block");
+            const int j0 = reg_bit(bits[l0]), j1 = reg_bit(bits[l1]);
+            const int hi = std::max(j0, j1), lo = std::min(j0, j1);
+            r.code = 5 + hi * (hi - 1) / 2 + lo;
+            for (int rr = 0; rr < 4; ++rr)
+                for (int cc = 0; cc < 4; ++cc) {
+                    // record index bit 1 <-> register bit hi; the caller's index bit 1 <-> leg 0
+                    const int ur = j0 > j1 ? rr : ((rr & 1) << 1) | (rr >> 1), uc = j0 > j1 ? cc : ((cc & 1) << 1) | (cc >> 1);
+                    r.m[2 * (rr * 4 + cc)] = m[2 * (ur * 4 + uc)];
+                    r.m[2 * (rr * 4 + cc) + 1] = m[2 * (ur * 4 + uc) + 1];
+                }
+            m += 32;
+        } else {
+            return QSV_UNHANDLED_KQ;
+        }
+    }
+    std::vector<int> ins(high);
+    ins.insert(ins.end(), standin.begin(), standin.end());
+    std::sort(ins.begin(), ins.end());
+    StageRef staged;
+    int rc = qsvk_stage(st, rec.data(), sizeof(SeqGate) * rec.size(), off.data(), sizeof(uint64_t) * D, &staged);
+    if (rc) return rc;
+    const SeqGate *dev_g = reinterpret_cast<const SeqGate *>(staged.dev);
+    const uint64_t *dev_off = reinterpret_cast<const uint64_t *>(staged.dev + qsv_pad16(sizeof(SeqGate) * rec.size()));
+    const bool nt = st->nontemporal != 0;
+    const uint64_t per_launch = 0x00ffffffull * QSV_BLOCK;
+    if (KL == 0) {
+        BigArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.W = W;
+        g.nins = static_cast<int>(ins.size());
+        for (size_t j = 0; j < ins.size(); ++j) g.pos[j] = static_cast<uint32_t>(ins[j]);
+        g.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : 8;
+        snprintf(st->last_kernel, sizeof(st->last_kernel), "k_seq_big<%s>", nt ? "true" : "false");
+        for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
+            const dim3 gd(grid_for(std::min(per_launch, g.W - g.w0), QSV_BLOCK, 0)), bd(QSV_BLOCK);
+            if (nt) hipLaunchKernelGGL(k_seq_big<true>, gd, bd, 0, st->stream, st->data, g, dev_g, n_gates, dev_off);
+            else hipLaunchKernelGGL(k_seq_big<false>, gd, bd, 0, st->stream, st->data, g, dev_g, n_gates, dev_off);
+            rc = check_launch();
+            if (rc) return rc;
+        }
+        return qsvk_stage_done(st, staged);
+    }
+    LdsArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.W = W;
+    g.nins = static_cast<int>(ins.size());
+    for (size_t j = 0; j < ins.size(); ++j) g.pos[j] = static_cast<uint32_t>(ins[j]);
+    for (int j = 0; j < KL; ++j) {
+        if (low[j] >= 3) {
+            g.abit[g.na] = low[j];
+            g.aE[g.na] = standin[j];
+            g.amask |= 1u << low[j];
+            ++g.na;
+        } else {
+            g.bmask |= 1u << low[j];
+        }
+    }
+    for (int v = 0; v < (1 << KB); ++v)
+        for (int j = 0; j < KB; ++j)
+            if ((v >> j) & 1) g.bdep[v] |= 1u << low[j];
+    g.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : 8;
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_seq_lds<%d, %s>", KB, nt ? "true" : "false");
+    for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
+        const dim3 gd(grid_for(std::min(per_launch, g.W - g.w0), QSV_BLOCK, 0)), bd(QSV_BLOCK);
+#define QSV_LAUNCH_SEQ(KBV)                                                                                           \
+    do {                                                                                                              \
+        if (nt) hipLaunchKernelGGL((k_seq_lds<KBV, true>), gd, bd, 0, st->stream, st->data, g, dev_g, n_gates, dev_off); \
+        else hipLaunchKernelGGL((k_seq_lds<KBV, false>), gd, bd, 0, st->stream, st->data, g, dev_g, n_gates, dev_off);   \
+    } while (0)
+        switch (KB) {
+            case 0: QSV_LAUNCH_SEQ(0); break;
+            case 1: QSV_LAUNCH_SEQ(1); break;
+            case 2: QSV_LAUNCH_SEQ(2); break;
+            default: QSV_LAUNCH_SEQ(3); break;
+        }
+#undef QSV_LAUNCH_SEQ
+        rc = check_launch();
+        if (rc) return rc;
+    }
+    return qsvk_stage_done(st, staged);
+}
 
 // k = 5 (complex matrices) and k = 6 on the matrix cores (k_dense_mfma).  bits[j] = bit position of matrix leg j (leg 0
 // most significant).

@@ -8,10 +8,13 @@ would cost one upload and one download per gate here).  Host arrays are only tou
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
 from . import _lib
+
+_SEQUENCE_WORK_ENV = int(os.environ.get("QSV_SEQUENCE_WORK", "0") or 0)   # see DeviceState.apply_sequence
 
 
 def _cbuf(a, n_complex: int | None = None) -> np.ndarray:
@@ -158,6 +161,8 @@ class DeviceState:
 
     def set_option(self, option: int, value: int) -> None:
         _lib.call("qsv_set_option", self._h, int(option), int(value))
+        if int(option) == _lib.OPT_SEQUENCE_WORK:
+            self._sequence_work = int(value) if int(value) >= 0 else _SEQUENCE_WORK_ENV
 
     def set_stream(self, stream: int) -> None:
         _lib.call("qsv_set_stream", self._h, C.c_void_p(stream))
@@ -178,6 +183,28 @@ class DeviceState:
         else:
             _lib.call("qsv_apply_kq", self._h, k, _ints(indices), _ptr(m))
         return self
+
+    def apply_sequence(self, indices, sources, matrix) -> "DeviceState":
+        """A fused block (``fusion.fuse_circuit``): ``matrix`` on qubits ``indices`` is the product of the gates
+        ``sources``.  With ``OPT_SEQUENCE_WORK`` (or ``$QSV_SEQUENCE_WORK``) set, 5-qubit blocks of 1- and 2-qubit gates
+        within that work limit are applied as that SEQUENCE in one pass over the register (``qsv_apply_sequence``: a
+        fraction of the dense block's arithmetic, but measured no faster -- off by default); everything else, and by
+        default every block, as the dense matrix."""
+        indices = [int(i) for i in indices]
+        if getattr(self, "_sequence_work", _SEQUENCE_WORK_ENV) > 0 and len(indices) == 5 and all(getattr(g, "matrix", None) is not None and 1 <= len(g.indices) <= 2
+                                     and np.shape(g.matrix) == (1 << len(g.indices),) * 2 for g in sources):
+            arity = [len(g.indices) for g in sources]
+            legs = []
+            for g in sources:
+                pos = [indices.index(int(q)) for q in g.indices]
+                legs += pos + [0] * (2 - len(pos))
+            mats = np.concatenate([np.ascontiguousarray(g.matrix, dtype=np.complex128).reshape(-1) for g in sources])
+            handled = C.c_int(0)
+            _lib.call("qsv_apply_sequence", self._h, 5, _ints(indices), len(sources), _ints(arity), _ints(legs), _ptr(mats),
+                      C.byref(handled))
+            if handled.value:
+                return self
+        return self.apply_matrix(matrix, indices)
 
     def apply_diagonal(self, diagonal, indices) -> "DeviceState":
         indices = [int(i) for i in indices]
@@ -371,6 +398,9 @@ class DensityState(DeviceState):
         DeviceState.apply_matrix(self, matrix, indices)
         DeviceState.apply_matrix(self, np.conjugate(matrix), [n + q for q in indices])
         return self
+
+    def apply_sequence(self, indices, sources, matrix) -> "DensityState":
+        return self.apply_matrix(matrix, indices)       # U rho U^dagger: both sides, as the dense block
 
     def purity(self) -> float:
         """``tr(rho rho)`` for a hermitian ``rho`` (``npq.purity``): the squared norm of the flattened register."""

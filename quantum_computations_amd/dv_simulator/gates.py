@@ -112,6 +112,9 @@ class Gate:
         if self.matrix.shape[0] != self.matrix.shape[1]:
             raise ValueError("new_ordering must be a permutation of all qubits")  # as expand_gate would
         if is_device_register(state):
+            sources = getattr(self, "sources", None)        # a fused block (fusion.py) knows the gates it was made of
+            if sources and hasattr(state, "apply_sequence"):
+                return state.apply_sequence(self.indices, sources, self.matrix)
             return state.apply_matrix(self.matrix, self.indices)
         state = np.asarray(state)
         if state.ndim == 1:

@@ -113,6 +113,31 @@ int main() {
             EXPECT(qsv_apply_kq(st, 7, qs.data(), m2.data()) == QSV_EINVAL);
             EXPECT(qsv_apply_kq(st, 0, qs.data(), m2.data()) == QSV_EINVAL);
         }
+        // ---- fused 5-qubit blocks as gate sequences: off by default, every placement once allowed ------------------
+        if (n >= 5) {
+            const int arity[4] = {2, 1, 2, 1}, legs[8] = {0, 4, 3, 0, 2, 1, 1, 0}, bad_legs[8] = {0, 5, 3, 0, 2, 1, 1, 0};
+            std::vector<double> mats;
+            for (int a : arity) {
+                const std::vector<double> m = matrix(1 << a);
+                mats.insert(mats.end(), m.begin(), m.end());
+            }
+            int handled = 7;
+            std::vector<int> first = {4, 0, 2, 1, 3};
+            EXPECT(qsv_apply_sequence(st, 5, first.data(), 4, arity, legs, mats.data(), &handled) == QSV_OK && handled == 0);
+            EXPECT(qsv_set_option(st, QSV_OPT_SEQUENCE_WORK, 1 << 20) == QSV_OK);
+            for (int shift = 0; shift + 5 <= n; ++shift) {
+                std::vector<int> qs(5);
+                for (int j = 0; j < 5; ++j) qs[j] = shift + (j * 3 + 1) % 5;
+                EXPECT(qsv_apply_sequence(st, 5, qs.data(), 4, arity, legs, mats.data(), &handled) == QSV_OK);
+                EXPECT(handled == (n >= 11 ? 1 : 0));       // needs 64 work items and stand-in bits above the lane bits
+            }
+            EXPECT(qsv_apply_sequence(st, 5, first.data(), 4, arity, bad_legs, mats.data(), &handled) == (n >= 11 ? QSV_EINVAL : QSV_OK));
+            EXPECT(qsv_set_option(st, QSV_OPT_SEQUENCE_WORK, 1024) == QSV_OK);          // this sequence costs 1536
+            EXPECT(qsv_apply_sequence(st, 5, first.data(), 4, arity, legs, mats.data(), &handled) == QSV_OK && handled == 0);
+            EXPECT(qsv_apply_sequence(st, 5, first.data(), 0, arity, legs, mats.data(), &handled) == QSV_EINVAL);
+            EXPECT(qsv_apply_sequence(st, 5, first.data(), 4, arity, legs, mats.data(), nullptr) == QSV_EINVAL);
+            EXPECT(qsv_set_option(st, QSV_OPT_SEQUENCE_WORK, -1) == QSV_OK && qsv_set_option(st, QSV_OPT_SEQUENCE_WORK, -2) == QSV_EINVAL);
+        }
         // ---- controlled gates and multi-controlled phases with many controls --------------------------------------
         if (n >= 2) {
             for (int nc = 1; nc < n && nc <= 8; ++nc) {

@@ -305,6 +305,73 @@ def test_complex_blocks_in_three_and_four_multiplications(product):
     assert all(three.values()) if product == 3 else not any(three.values()), (three, seen)
 
 
+def test_fused_blocks_as_gate_sequences_every_low_target_set():
+    """Round 3: a fused 5-qubit block is applied as the sequence of its 1- and 2-qubit source gates in one pass
+    (``qsv_apply_sequence`` -> k_seq_big / k_seq_lds<KB>) instead of its dense 32 x 32 product.  Every set of block qubits
+    below bit 6 (all subsets of the six lane bits, up to five), the others on random high bits, legs in any order, gates
+    on every leg / ordered pair of legs incl. CX, CZ, SWAP; against the oracle applying the source gates one by one."""
+    import itertools
+
+    from quantum_computations_amd.fusion import fuse_circuit
+    n, k = 13, 5
+    rng = np.random.default_rng(77)
+    ket = W.random_ket(n, 32)
+    dev = DeviceState.from_numpy(ket)
+    dev.set_option(_lib.OPT_SEQUENCE_WORK, 1 << 20)          # every sequence as a sequence, whatever its length
+    want = ket
+    kernels = set()
+    fixed = [G.CX, G.CZ, G.SWAP]
+    for n_low in range(k + 1):
+        for low_bits in itertools.combinations(range(6), n_low):
+            high_bits = [int(b) for b in rng.choice(np.arange(6, n), size=k - n_low, replace=False)]
+            bits = list(low_bits) + high_bits
+            rng.shuffle(bits)
+            qs = [n - 1 - b for b in bits]
+            sources = []
+            for _ in range(int(rng.integers(2, 9))):
+                if rng.random() < 0.45:
+                    sources.append(G.Gate([int(rng.choice(qs))], W.haar_unitary(2, rng)))
+                else:
+                    a, b = (int(q) for q in rng.choice(qs, size=2, replace=False))
+                    pick = int(rng.integers(0, 5))
+                    sources.append(fixed[pick](a, b) if pick < 3 else G.Gate([a, b], W.haar_unitary(4, rng)))
+            sources.append(G.Gate([qs[0], qs[4]], W.haar_unitary(4, rng)))       # every block touches all five qubits:
+            sources.append(G.Gate([qs[1], qs[2]], W.haar_unitary(4, rng)))       # legs 0-4, 1-2, 3
+            sources.append(G.Gate([qs[3]], W.haar_unitary(2, rng)))
+            fused = fuse_circuit(sources, 5, n_qubits=n)
+            assert len(fused) == 1 and sorted(fused[0].indices) == sorted(qs) and len(fused[0].sources) == len(sources)
+            fused[0].apply(dev)
+            kernels.add(dev.last_kernel())
+            for g in sources:
+                want = O.apply_gate(want, np.asarray(g.matrix, dtype=complex), list(g.indices))
+            assert maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL, (bits, dev.last_kernel())
+    assert kernels == {"k_seq_big<true>", "k_seq_lds<0, true>", "k_seq_lds<1, true>", "k_seq_lds<2, true>", "k_seq_lds<3, true>"}, kernels
+    # the dense product gives the same state (to rounding); a block with a 3-qubit source gate has no sequence form
+    block = fused[0]
+    a = DeviceState.from_numpy(ket)
+    b = DeviceState.from_numpy(ket)
+    a.set_option(_lib.OPT_SEQUENCE_WORK, 1 << 20)
+    block.apply(a)
+    b.apply_matrix(block.matrix, block.indices)
+    assert a.last_kernel().startswith("k_seq_") and not b.last_kernel().startswith("k_seq_")
+    assert maxdiff(a.to_numpy(), b.to_numpy()) < GATE_TOL * 10
+    # the work limit: by default a sequence costing more than the dense block's share goes as the dense block; 0 = never
+    work = sum(256 if len(g.indices) == 1 else 512 for g in block.sources)
+    a.set_option(_lib.OPT_SEQUENCE_WORK, work - 1)
+    block.apply(a)
+    assert not a.last_kernel().startswith("k_seq_")
+    a.set_option(_lib.OPT_SEQUENCE_WORK, work)
+    block.apply(a)
+    assert a.last_kernel().startswith("k_seq_")
+    a.set_option(_lib.OPT_SEQUENCE_WORK, 0)
+    block.apply(a)
+    assert not a.last_kernel().startswith("k_seq_")
+    a.set_option(_lib.OPT_SEQUENCE_WORK, 1 << 20)
+    block.sources = block.sources + [G.Gate([qs[0], qs[1], qs[2]], np.identity(8))]
+    block.apply(a)
+    assert a.last_kernel().startswith(("k_dense_big<5", "k_dense_lds<5")), a.last_kernel()
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("k", [3, 4, 5])
 def test_register_blocked_kq_every_low_target_set(k, variant):
