@@ -251,7 +251,12 @@ int qsv_tensor_svd_split(int device, void *hip_stream, void *dev_theta, uint64_t
  * `power_iterations` passes (mps.py:5-50), SVD of the small projection, first max_bond_dim triplets, then the
  * truncation rule above.  `dev_omega` holds the test matrix the reference would draw,
  * rng.normal(size=(min(rows, cols), probes)), as complex128 in COLUMN-major order, so that a seeded run consumes
- * the same random stream and lands on the same subspace.  `dev_theta` is not modified. */
+ * the same random stream and lands on the same subspace.  `dev_theta` is not modified.
+ * `dev_omega` may be NULL on a first call: converting and uploading 10^5 normal deviates costs more than a split that
+ * never reads them (under a loose tolerance a verified low-rank route with fixed probes decides most splits).  A caller
+ * whose generator is shared with the rest of the simulation still has to DRAW them, as mps.py:14-15 does -- it can do so
+ * while this call runs.  *rank = QSV_RANK_NEEDS_OMEGA then means nothing was computed: call again with the test matrix. */
+#define QSV_RANK_NEEDS_OMEGA UINT64_MAX
 int qsv_tensor_rsvd_split(int device, void *hip_stream, const void *dev_theta, uint64_t rows, uint64_t cols,
                           int64_t max_bond_dim, int probes, int power_iterations, const void *dev_omega,
                           double abs_err, double rel_err, void *dev_m1, void *dev_m2, uint64_t capacity,

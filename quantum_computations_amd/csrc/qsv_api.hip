@@ -928,7 +928,7 @@ int qsv_tensor_rsvd_split(int device, void *hip_stream, const void *dev_theta, u
                           int64_t max_bond_dim, int probes, int power_iterations, const void *dev_omega,
                           double abs_err, double rel_err, void *dev_m1, void *dev_m2, uint64_t capacity,
                           uint64_t *rank, double *singular_values) {
-    if (!dev_theta || !dev_omega || !dev_m1 || !dev_m2 || !rank) return qsv_fail(QSV_EINVAL, "null pointer");
+    if (!dev_theta || !dev_m1 || !dev_m2 || !rank) return qsv_fail(QSV_EINVAL, "null pointer");   // dev_omega may be NULL
     if (rows == 0 || cols == 0) return qsv_fail(QSV_EINVAL, "empty matrix");
     if (max_bond_dim < 1 || probes < max_bond_dim || power_iterations < 0)
         return qsv_fail(QSV_EINVAL, "need max_bond_dim >= 1, probes >= max_bond_dim, power_iterations >= 0");

@@ -100,25 +100,29 @@ __device__ __forceinline__ amp_t plain_mul(amp_t a, amp_t b) {
 }
 
 // partials[block][i * l + j] = sum over the block's rows of conj(Y[r, i]) * Y[r, j]   (Y column-major, ld n)
+// BANDS > 1: blockIdx.y takes one of BANDS slices of the entries (a short panel has too few row tiles to fill the chip,
+// and one workgroup per tile spends 16 entries x 64 rows of dependent FMAs per thread)
+template <int BANDS>
 __global__ __launch_bounds__(256) void k_panel_gram(const amp_t *__restrict__ Y, uint64_t n, int l,
                                                    amp_t *__restrict__ partials, const int *__restrict__ settled) {
     if (settled && *settled) return;     // the previous round found the panel orthonormal already
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     amp_t *tile = reinterpret_cast<amp_t *>(smem_raw);   // [l][PANEL_PITCH]
-    const int t = threadIdx.x, entries = l * l;
-    amp_t acc[LMAX * LMAX / 256];
+    constexpr int PER_THREAD = LMAX * LMAX / 256 / BANDS;
+    const int t = threadIdx.x + 256 * PER_THREAD * blockIdx.y, entries = l * l;
+    amp_t acc[PER_THREAD];
 #pragma unroll
-    for (int k = 0; k < LMAX * LMAX / 256; ++k) acc[k] = amp_t{0.0, 0.0};
+    for (int k = 0; k < PER_THREAD; ++k) acc[k] = amp_t{0.0, 0.0};
     for (uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * PANEL_ROWS; r0 < n;
          r0 += static_cast<uint64_t>(gridDim.x) * PANEL_ROWS) {
         __syncthreads();
-        for (int idx = t; idx < l * PANEL_ROWS; idx += 256) {
+        for (int idx = threadIdx.x; idx < l * PANEL_ROWS; idx += 256) {
             const int c = idx / PANEL_ROWS, r = idx % PANEL_ROWS;
             tile[c * PANEL_PITCH + r] = r0 + r < n ? Y[static_cast<uint64_t>(c) * n + r0 + r] : amp_t{0.0, 0.0};
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < LMAX * LMAX / 256; ++k) {
+        for (int k = 0; k < PER_THREAD; ++k) {
             const int e = t + 256 * k;
             if (e < entries) {
                 const amp_t *ci = tile + (e / l) * PANEL_PITCH, *cj = tile + (e % l) * PANEL_PITCH;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void k_panel_gram(const amp_t *__restrict__ Y,
         }
     }
 #pragma unroll
-    for (int k = 0; k < LMAX * LMAX / 256; ++k) {
+    for (int k = 0; k < PER_THREAD; ++k) {
         const int e = t + 256 * k;
         if (e < entries) partials[static_cast<size_t>(blockIdx.x) * entries + e] = acc[k];
     }
@@ -392,7 +396,10 @@ __global__ __launch_bounds__(256) void k_panel_solve(amp_t *__restrict__ Y, uint
 // SVD of the l x l matrix R (row-major) by one-sided Jacobi in one workgroup: R V = U S.  Column pairs follow a
 // round-robin tournament (l/2 disjoint pairs per step, a few threads per pair); outputs are sorted by decreasing
 // singular value: U, V column-major (l x l), S (l doubles).
-__global__ __launch_bounds__(256) void k_small_svd(const amp_t *__restrict__ R, int l, amp_t *__restrict__ U,
+// (1024 threads: 16 per column pair at l = 64 -- a team then reads 256 contiguous bytes of a column, one conflict-free LDS
+// pass, where the 8-thread teams of a 256-thread workgroup collided two by two -- and four rows per thread per rotation)
+constexpr int SVD_THREADS = 1024;
+__global__ __launch_bounds__(SVD_THREADS) void k_small_svd(const amp_t *__restrict__ R, int l, amp_t *__restrict__ U,
                                                   double *__restrict__ S, amp_t *__restrict__ V) {
     __shared__ amp_t W[LMAX * LMAX];    // working columns, column-major
     __shared__ amp_t Vw[LMAX * LMAX];
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(256) void k_small_svd(const amp_t *__restrict__ R, 
     __shared__ int order[LMAX];
     __shared__ int rotated;
     const int t = threadIdx.x;
-    for (int e = t; e < l * l; e += 256) {
+    for (int e = t; e < l * l; e += SVD_THREADS) {
         const int c = e / l, r = e % l;
         // the working matrix is R^H: its columns are the conjugated rows of the upper triangle, which the one-sided sweeps
         // orthogonalise in fewer passes than the columns of R itself (the triangle's rows are already nearly graded);
@@ -410,8 +417,8 @@ __global__ __launch_bounds__(256) void k_small_svd(const amp_t *__restrict__ R, 
         Vw[c * l + r] = amp_t{r == c ? 1.0 : 0.0, 0.0};
     }
     const int lp = (l + 1) & ~1, pairs = lp / 2;
-    int team = 1;                       // threads per pair: a power of two, pairs * team <= 256, team <= 64
-    while (team * 2 * pairs <= 256 && team < 64) team *= 2;
+    int team = 1;                       // threads per pair: a power of two, pairs * team <= SVD_THREADS, team <= 64
+    while (team * 2 * pairs <= SVD_THREADS && team < 64) team *= 2;
     const int pair = t / team, member = t % team;
     const double eps = 2.220446049250313e-16;
     for (int sweep = 0; sweep < 40; ++sweep) {
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(256) void k_small_svd(const amp_t *__restrict__ R, 
         if (!rotated) break;
     }
     __syncthreads();
-    for (int c = t; c < l; c += 256) {
+    for (int c = t; c < l; c += SVD_THREADS) {
         double s = 0.0;
         for (int r = 0; r < l; ++r) s += W[c * l + r].x * W[c * l + r].x + W[c * l + r].y * W[c * l + r].y;
         sigma[c] = sqrt(s);
@@ -489,14 +496,14 @@ __global__ __launch_bounds__(256) void k_small_svd(const amp_t *__restrict__ R, 
         }
     }
     __syncthreads();
-    for (int e = t; e < l * l; e += 256) {
+    for (int e = t; e < l * l; e += SVD_THREADS) {
         const int rank = e / l, r = e % l, c = order[rank];
         const double s = sigma[c];
         const amp_t w = W[c * l + r];
         U[rank * l + r] = s > 0.0 ? amp_t{w.x / s, w.y / s} : amp_t{0.0, 0.0};
         V[rank * l + r] = Vw[c * l + r];
     }
-    for (int rank = t; rank < l; rank += 256) S[rank] = sigma[order[rank]];
+    for (int rank = t; rank < l; rank += SVD_THREADS) S[rank] = sigma[order[rank]];
 }
 
 // ---- the same one-sided Jacobi SVD for factors wider than 64 columns (up to WIDE_FACTOR): the working matrices live in
@@ -800,7 +807,7 @@ constexpr int SK_SLAB = 32;           // k values per LDS slab of Q
 template <int T>                      // T = number of 16-column tiles of the panel (l <= 16 T)
 __global__ __launch_bounds__(256) void k_skinny_nn(const amp_t *__restrict__ A, const amp_t *__restrict__ Q,
                                                   amp_t *__restrict__ Y, uint64_t n, uint64_t m, int l,
-                                                  double im_sign) {
+                                                  double im_sign, amp_t *__restrict__ shares) {
     __shared__ amp_t slab[2][SK_SLAB][16 * T + 1];   // +1: the column-wise slab stores would otherwise hit one bank
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -885,6 +892,8 @@ __global__ __launch_bounds__(256) void k_skinny_nn(const amp_t *__restrict__ A, 
                 amp_t *dst = Y + static_cast<uint64_t>(col) * n + r;
                 if (gridDim.y == 1) {
                     *dst = amp_t{cre[j][reg], cim[j][reg]};
+                } else if (shares) {        // k_sum_shares adds the shares in order
+                    shares[(static_cast<uint64_t>(blockIdx.y) * l + col) * n + r] = amp_t{cre[j][reg], cim[j][reg]};
                 } else {
                     atomicAdd(reinterpret_cast<double *>(dst), cre[j][reg]);
                     atomicAdd(reinterpret_cast<double *>(dst) + 1, cim[j][reg]);
@@ -897,7 +906,7 @@ __global__ __launch_bounds__(256) void k_skinny_nn(const amp_t *__restrict__ A, 
 template <int T>
 __global__ __launch_bounds__(256) void k_skinny_cn(const amp_t *__restrict__ A, const amp_t *__restrict__ Q,
                                                   amp_t *__restrict__ Y, uint64_t n, uint64_t m, int l,
-                                                  double im_sign) {
+                                                  double im_sign, amp_t *__restrict__ shares) {
     __shared__ amp_t slab[2][SK_SLAB][16 * T + 1];   // +1: the column-wise slab stores would otherwise hit one bank
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -985,6 +994,8 @@ __global__ __launch_bounds__(256) void k_skinny_cn(const amp_t *__restrict__ A, 
                 amp_t *dst = Y + static_cast<uint64_t>(pc) * m + r;
                 if (gridDim.y == 1) {
                     *dst = amp_t{cre[j][reg], cim[j][reg]};
+                } else if (shares) {
+                    shares[(static_cast<uint64_t>(blockIdx.y) * l + pc) * m + r] = amp_t{cre[j][reg], cim[j][reg]};
                 } else {
                     atomicAdd(reinterpret_cast<double *>(dst), cre[j][reg]);
                     atomicAdd(reinterpret_cast<double *>(dst) + 1, cim[j][reg]);
@@ -999,29 +1010,68 @@ __global__ __launch_bounds__(256) void k_skinny_cn(const amp_t *__restrict__ A, 
 // Returns false when the shape is outside what the kernels take (l > 64) so that the caller can use the library instead.
 constexpr int WIDE_MAX = 256;        // widest panel the blocked (64-column) forms take
 
+constexpr unsigned SKINNY_MAX_SHARES = 16;
+
+// Y[i] = shares[0][i] + shares[1][i] + ... in that order (the k ranges of a split-K skinny product)
+__global__ __launch_bounds__(256) void k_sum_shares(const amp_t *__restrict__ shares, amp_t *__restrict__ Y, uint64_t count,
+                                                   int n_shares) {
+    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    if (i >= count) return;
+    amp_t v[SKINNY_MAX_SHARES];
+#pragma unroll
+    for (int s = 0; s < static_cast<int>(SKINNY_MAX_SHARES); ++s)
+        if (s < n_shares) v[s] = shares[static_cast<uint64_t>(s) * count + i];
+    amp_t sum = v[0];
+#pragma unroll
+    for (int s = 1; s < static_cast<int>(SKINNY_MAX_SHARES); ++s)
+        if (s < n_shares) {
+            sum.x += v[s].x;
+            sum.y += v[s].y;
+        }
+    Y[i] = sum;
+}
+
+// `shares` (optional, room for `share_amps` amplitudes): workspace that lets a product with few output rows cut its k
+// range into up to 16 shares (one workgroup each, summed in order by k_sum_shares) instead of two
 bool skinny_gemm(hipStream_t stream, bool transpose, bool conjugate, const amp_t *A, const amp_t *Q, amp_t *Y,
-                 uint64_t n, uint64_t m, int l) {
+                 uint64_t n, uint64_t m, int l, amp_t *shares = nullptr, uint64_t share_amps = 0) {
     if (l < 1 || l > WIDE_MAX) return false;
     const uint64_t out_rows = transpose ? m : n;
     if (l > 64) {        // panels wider than the kernels' 64 columns: one pass over A per 64-column slice
         const uint64_t q_rows = transpose ? n : m;
         for (int c0 = 0; c0 < l; c0 += 64)
             if (!skinny_gemm(stream, transpose, conjugate, A, Q + static_cast<uint64_t>(c0) * q_rows,
-                             Y + static_cast<uint64_t>(c0) * out_rows, n, m, l - c0 < 64 ? l - c0 : 64))
+                             Y + static_cast<uint64_t>(c0) * out_rows, n, m, l - c0 < 64 ? l - c0 : 64, shares, share_amps))
                 return false;
         return true;
     }
     const int tiles = (l + 15) / 16;
     const unsigned row_blocks = static_cast<unsigned>((out_rows + 63) / 64);
-    // one wave per SIMD cannot hide its own load latency: below two workgroups per CU the k range is cut in two
-    const unsigned split = row_blocks < 512 && (transpose ? n : m) >= 4 * SK_SLAB ? 2 : 1;
-    if (split > 1 && hipMemsetAsync(Y, 0, sizeof(amp_t) * out_rows * l, stream) != hipSuccess) return false;
+    const uint64_t depth = transpose ? n : m;        // the summed dimension
+    // one wave per SIMD cannot hide its own load latency: below two workgroups per CU the k range is cut in two (the two
+    // partial sums meet in a zero-initialised Y through atomic adds: a + b does not depend on which arrives first) -- or,
+    // with a workspace, into as many shares as give every CU two workgroups, each at least four slabs deep
+    unsigned split = row_blocks < 512 && depth >= 4 * SK_SLAB ? 2 : 1;
+    bool shared_out = false;
+    if (split > 1 && shares && row_blocks < 256) {
+        unsigned want = (512 + row_blocks - 1) / row_blocks;
+        const uint64_t deepest = depth / (4 * SK_SLAB);
+        if (want > SKINNY_MAX_SHARES) want = SKINNY_MAX_SHARES;
+        if (want > deepest) want = static_cast<unsigned>(deepest);
+        while (want > 2 && static_cast<uint64_t>(want) * out_rows * l > share_amps) --want;
+        if (want > 2 && static_cast<uint64_t>(want) * out_rows * l <= share_amps) {
+            split = want;
+            shared_out = true;
+        }
+    }
+    if (split > 1 && !shared_out && hipMemsetAsync(Y, 0, sizeof(amp_t) * out_rows * l, stream) != hipSuccess) return false;
     const dim3 grid(row_blocks, split), block(256);
+    amp_t *share_arg = shared_out ? shares : nullptr;
     // k_skinny_nn multiplies by (re, im_sign * im); k_skinny_cn by the conjugate of that
     const double im_sign = transpose ? (conjugate ? 1.0 : -1.0) : (conjugate ? -1.0 : 1.0);
-#define QSV_SKINNY(T)                                                                                              \
-    if (transpose) hipLaunchKernelGGL(k_skinny_cn<T>, grid, block, 0, stream, A, Q, Y, n, m, l, im_sign);          \
-    else hipLaunchKernelGGL(k_skinny_nn<T>, grid, block, 0, stream, A, Q, Y, n, m, l, im_sign)
+#define QSV_SKINNY(T)                                                                                                    \
+    if (transpose) hipLaunchKernelGGL(k_skinny_cn<T>, grid, block, 0, stream, A, Q, Y, n, m, l, im_sign, share_arg);     \
+    else hipLaunchKernelGGL(k_skinny_nn<T>, grid, block, 0, stream, A, Q, Y, n, m, l, im_sign, share_arg)
     switch (tiles) {
         case 1: QSV_SKINNY(1); break;
         case 2: QSV_SKINNY(2); break;
@@ -1029,17 +1079,27 @@ bool skinny_gemm(hipStream_t stream, bool transpose, bool conjugate, const amp_t
         default: QSV_SKINNY(4); break;
     }
 #undef QSV_SKINNY
+    if (shared_out) {
+        const uint64_t count = out_rows * l;
+        hipLaunchKernelGGL(k_sum_shares, dim3(static_cast<unsigned>((count + 255) / 256)), dim3(256), 0, stream, shares, Y,
+                           count, static_cast<int>(split));
+    }
     return hipGetLastError() == hipSuccess;
 }
 
 // Shifted CholeskyQR3 of the column-major (n x l) panel Y, in place.  `r_total` (l x l, row-major, may be null) receives
 // the triangular factor with  Y_in = Y_out * r_total.
+// `rounds` = 2 for the intermediate panels of the power iteration: only their SPAN enters the next product, and after the
+// shifted round and one plain round the basis is conditioned like O(1) (absent directions dropped) -- the third round,
+// which takes the Gram matrix from ~1e-8 of the identity to rounding level, matters for the final Q and for Qb alone.
 int panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t *partials, amp_t *r_factor,
-                         amp_t *r_total, int *flags = nullptr) {
+                         amp_t *r_total, int *flags = nullptr, int rounds = 3) {
     const size_t lds = sizeof(amp_t) * l * PANEL_PITCH;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
-        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_panel_gram),
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_panel_gram<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LMAX * PANEL_PITCH * sizeof(amp_t))));
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_panel_gram<4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(LMAX * PANEL_PITCH * sizeof(amp_t))));
         raised = true;
     }
@@ -1052,11 +1112,12 @@ int panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t 
     const uint64_t tiles = (n + PANEL_ROWS - 1) / PANEL_ROWS;
     const int gram_blocks = static_cast<int>(tiles < GRAM_BLOCKS ? tiles : GRAM_BLOCKS);
     const unsigned apply_blocks = static_cast<unsigned>(tiles < 4096 ? tiles : 4096);
-    for (int round = 0; round < 3; ++round) {
+    for (int round = 0; round < rounds; ++round) {
         // flags[round] tells this round's kernels to return at once; the factor kernel of a round writes flags[round + 1]
         const int *skip = flags && round > 0 ? flags + round : nullptr;
         int *next = flags && round < 2 ? flags + round + 1 : nullptr;
-        hipLaunchKernelGGL(k_panel_gram, dim3(gram_blocks), dim3(256), lds, stream, Y, n, l, partials, skip);
+        if (tiles <= 256) hipLaunchKernelGGL(k_panel_gram<4>, dim3(gram_blocks, 4), dim3(256), lds, stream, Y, n, l, partials, skip);
+        else hipLaunchKernelGGL(k_panel_gram<1>, dim3(gram_blocks), dim3(256), lds, stream, Y, n, l, partials, skip);
         hipLaunchKernelGGL(k_panel_factor, dim3(1), dim3(FACTOR_THREADS), 0, stream, partials, gram_blocks, l, n, round == 0,
                            round == 0 ? nullptr : r_total, r_total, r_factor, skip, next);
         hipLaunchKernelGGL(k_panel_solve, dim3(apply_blocks), dim3(256), lds + sizeof(amp_t) * l * l, stream, Y, n, l,
@@ -1169,8 +1230,8 @@ __global__ __launch_bounds__(256) void k_place_block(amp_t *__restrict__ out, in
 // `r_total` (l x l row-major, may be null) receives the block upper triangular factor with Y_in = Y_out * r_total;
 // `scratch` holds 2 * 64 * 64 amplitudes.
 int wide_panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t *partials, amp_t *scratch,
-                              amp_t *r_total, int *flags) {
-    if (l <= LMAX) return panel_orthonormalise(stream, Y, n, l, partials, scratch, r_total, flags);
+                              amp_t *r_total, int *flags, int rounds = 3) {
+    if (l <= LMAX) return panel_orthonormalise(stream, Y, n, l, partials, scratch, r_total, flags, rounds);
     static bool raised = false;
     if (!raised) {
         const int big = static_cast<int>((2 * LMAX * PANEL_PITCH) * sizeof(amp_t));
@@ -1199,7 +1260,7 @@ int wide_panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, a
             }
         // the block itself; its triangular factor goes on the diagonal of r_total
         amp_t *diag = r_total ? cross : nullptr;       // w x w, row-major, reuses the cross buffer
-        const int rc = panel_orthonormalise(stream, Yj, n, w, partials, block_factor, diag, flags);
+        const int rc = panel_orthonormalise(stream, Yj, n, w, partials, block_factor, diag, flags, rounds);
         if (rc) return rc;
         if (r_total) hipLaunchKernelGGL(k_place_block, dim3(4), dim3(256), 0, stream, r_total, l, c0, c0, diag, w, w);
     }
@@ -1307,14 +1368,17 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
     const uint64_t L = static_cast<uint64_t>(l);
     DeviceBuffers buf;
     const uint64_t block = L < LMAX ? L : LMAX, scratch_amps = 2 * LMAX * LMAX;
-    buf.reserve(device, sizeof(amp_t) * ((n + m) * (L + static_cast<uint64_t>(k_keep)) + (verify ? n * L : 0) +
+    // the k-range shares of the skinny products: only matrices with few 64-row blocks use them (see skinny_gemm)
+    const uint64_t share_amps = n < 256 * 64 ? SKINNY_MAX_SHARES * n * (L < 64 ? L : 64) : 0;
+    buf.reserve(device, sizeof(amp_t) * ((n + m) * (L + static_cast<uint64_t>(k_keep)) + (verify ? n * L : 0) + share_amps +
                                          GRAM_BLOCKS * block * block + scratch_amps + 5 * L * L) + 32 * L + 16384 + 8 * 1024);
-    amp_t *Qn = nullptr, *Qm = nullptr, *partials = nullptr, *small = nullptr, *UA = nullptr, *VA = nullptr;
+    amp_t *Qn = nullptr, *Qm = nullptr, *partials = nullptr, *small = nullptr, *UA = nullptr, *VA = nullptr, *shares = nullptr;
     double *dS = nullptr;
     // small: block scratch (2 x 64 x 64) | r_total | U_r | V_r | library scratch, each L x L
     if (!buf.alloc(&Qn, sizeof(amp_t) * n * L) || !buf.alloc(&Qm, sizeof(amp_t) * m * L) ||
         !buf.alloc(&partials, sizeof(amp_t) * GRAM_BLOCKS * block * block) ||
-        !buf.alloc(&small, sizeof(amp_t) * (scratch_amps + 5 * L * L)) || !buf.alloc(&dS, sizeof(double) * (2 * L + 6)))
+        !buf.alloc(&small, sizeof(amp_t) * (scratch_amps + 5 * L * L)) || !buf.alloc(&dS, sizeof(double) * (2 * L + 6)) ||
+        (share_amps && !buf.alloc(&shares, sizeof(amp_t) * share_amps)))
         return qsv_fail(QSV_ENOMEM, "device allocation of the randomized-SVD workspace failed");
     amp_t *r_factor = small, *r_total = small + scratch_amps, *Ur = r_total + L * L, *Vr = Ur + L * L, *lib = Vr + L * L;
     int *flags = reinterpret_cast<int *>(dS + 2 * L + 2);     // round-skipping flags of the panel kernels (4 ints)
@@ -1337,24 +1401,28 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
     const rocblas_int ld = static_cast<rocblas_int>(cols);       // leading dimension of M
     auto times_a = [&](const amp_t *panel, amp_t *out) {          // out (n x l) = A panel (m x l)
         if (wide)   // A = M (n x m)
-            return skinny_gemm(stream, false, false, M, panel, out, n, m, l) ||
+            return skinny_gemm(stream, false, false, M, panel, out, n, m, l, shares, share_amps) ||
                    gemm(N, N, ni, li, mi, M, ld, panel, mi, out, ni);
         // A = M^T with M (m x n)
-        return skinny_gemm(stream, true, false, M, panel, out, m, n, l) || gemm(T_, N, ni, li, mi, M, ld, panel, mi, out, ni);
+        return skinny_gemm(stream, true, false, M, panel, out, m, n, l, shares, share_amps) || gemm(T_, N, ni, li, mi, M, ld, panel, mi, out, ni);
     };
     auto times_ah = [&](const amp_t *panel, amp_t *out) {         // out (m x l) = A^H panel (n x l)
-        if (wide) return skinny_gemm(stream, true, true, M, panel, out, n, m, l) ||
+        if (wide) return skinny_gemm(stream, true, true, M, panel, out, n, m, l, shares, share_amps) ||
                          gemm(Cc, N, mi, li, ni, M, ld, panel, ni, out, mi);
         // A^H = conj(M): no library form for a plain conjugate, the kernels take every l <= 64 this path is entered with
-        return skinny_gemm(stream, false, true, M, panel, out, m, n, l);
+        return skinny_gemm(stream, false, true, M, panel, out, m, n, l, shares, share_amps);
     };
+    static const int between = [] {        // rounds of the panels in between (QSV_PANEL_ROUNDS=3: as the final ones)
+        const char *e = std::getenv("QSV_PANEL_ROUNDS");
+        return e && atoi(e) == 3 ? 3 : 2;
+    }();
     bool ok = times_a(omega, Qn);                                                                 // Y = A O
-    int rc = ok ? wide_panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr, flags) : QSV_OK;
+    int rc = ok ? wide_panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr, flags, q > 0 ? between : 3) : QSV_OK;
     for (int it = 0; ok && !rc && it < q; ++it) {
         ok = times_ah(Qn, Qm);                                                                    // Y = A^H Q
-        if (ok) rc = wide_panel_orthonormalise(stream, Qm, m, l, partials, r_factor, nullptr, flags);
+        if (ok) rc = wide_panel_orthonormalise(stream, Qm, m, l, partials, r_factor, nullptr, flags, between);
         ok = ok && !rc && times_a(Qm, Qn);                                                        // Y = A Q
-        if (ok) rc = wide_panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr, flags);
+        if (ok) rc = wide_panel_orthonormalise(stream, Qn, n, l, partials, r_factor, nullptr, flags, it + 1 < q ? between : 3);
     }
     // B^H = A^H Q = Qb Rb  (m x l);  Rb = Ur S Vr^H;  A ~ (Q Vr) S (Qb Ur)^H
     ok = ok && !rc && times_ah(Qn, Qm);
@@ -1362,7 +1430,7 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
     if (!ok) return qsv_fail(QSV_EHIP, "rocBLAS call failed in the randomized range finder");
     if (rc) return rc;
     if (L <= LMAX) {
-        hipLaunchKernelGGL(k_small_svd, dim3(1), dim3(256), 0, stream, r_total, l, Vr, dS, Ur);   // decomposes R^H: roles swap
+        hipLaunchKernelGGL(k_small_svd, dim3(1), dim3(SVD_THREADS), 0, stream, r_total, l, Vr, dS, Ur);   // decomposes R^H: roles swap
         QSV_HIP(hipGetLastError());
     } else {
         // wider than the one-workgroup Jacobi kernel: the same sweeps with the working matrices in global memory, one
@@ -1572,7 +1640,7 @@ int qsvg_rsvd_split(int device, hipStream_t stream, const amp_t *theta, uint64_t
     const uint64_t L = static_cast<uint64_t>(l), kk = L < m ? L : m;
     if (k_keep < 1 || L < static_cast<uint64_t>(k_keep) || L > m)
         return qsv_fail(QSV_EINVAL, "need 1 <= k <= l <= min(rows, cols)");
-    if (L <= LMAX && fused_panels_enabled())
+    if (omega && L <= LMAX && fused_panels_enabled())
         return rsvd_split_fused(a, h, device, stream, theta, rows, cols, k_keep, l, q, omega, abs_err, rel_err, m1, m2, capacity,
                                 rank_out, s_host);
     // More probes than the fused kernels take (max_bond_dim > 54, e.g. the 100 of the reference's GKP runs).  Under a
@@ -1593,6 +1661,10 @@ int qsvg_rsvd_split(int device, hipStream_t stream, const amp_t *theta, uint64_t
             return QSV_OK;
         }
         if (fast != QSV_UNDECIDED) return fast;
+    }
+    if (!omega) {      // the caller has not drawn the test matrix yet (it costs more than the route above): ask for it
+        *rank_out = QSV_RANK_NEEDS_OMEGA;
+        return QSV_OK;
     }
     if (L <= WIDE_MAX && fused_panels_enabled())      // 64-column blocks of probes, library SVD of the projected factor
         return rsvd_split_fused(a, h, device, stream, theta, rows, cols, k_keep, l, q, omega, abs_err, rel_err, m1, m2, capacity,

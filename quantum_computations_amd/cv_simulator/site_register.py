@@ -29,12 +29,14 @@ from __future__ import annotations
 
 import ctypes as C
 from collections import OrderedDict
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
 from .. import _lib
 
 OP_NONE, OP_TRANSPOSE, OP_CONJ_TRANSPOSE = 0, 1, 2
+_DRAW_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="qsv-omega")     # see SiteRegister._split
 
 
 _TORCH = None
@@ -238,12 +240,29 @@ class SiteRegister:
         if capped and max_bond_dim * 10 < full and cap >= 1:
             k = int(max_bond_dim)
             probes, power_iterations = k + 10, (7 if k < 0.1 * full else 4)
-            omega = np.random.default_rng(rng_seed).normal(0, 1, size=(full, probes))
-            dev_omega = self._upload(np.asfortranarray(omega).T)      # the transpose's C order = column-major omega
             s = np.empty(k, dtype=np.float64)
-            _lib.call("qsv_tensor_rsvd_split", self.device, self._stream(), self._p(theta), rows, cols, k, probes,
-                      power_iterations, self._p(dev_omega), float(abs_err), float(rel_err), self._p(m1), self._p(m2),
-                      cap, C.byref(rank), s.ctypes.data_as(C.c_void_p))
+            # The first call goes without the Gaussian test matrix: under a loose tolerance the library's verified
+            # low-rank route decides the split without reading it.  The reference draws it from default_rng(rng_seed)
+            # (mps.py:14-15): a Generator handed down by the simulator (gates.py passes its own) is advanced by that draw,
+            # so it is made in any case -- on a helper thread while the library works (both release the GIL) -- and only
+            # the conversion and upload wait for the library to ask; a seed or None creates a generator nobody else sees,
+            # and the draw itself waits too.
+            draw = lambda: np.random.default_rng(rng_seed).normal(0, 1, size=(full, probes))
+            pending = _DRAW_POOL.submit(draw) if isinstance(rng_seed, np.random.Generator) else None
+            dev_omega = None
+            try:
+                for attempt in range(2):
+                    _lib.call("qsv_tensor_rsvd_split", self.device, self._stream(), self._p(theta), rows, cols, k, probes,
+                              power_iterations, self._p(dev_omega) if dev_omega is not None else None, float(abs_err),
+                              float(rel_err), self._p(m1), self._p(m2), cap, C.byref(rank), s.ctypes.data_as(C.c_void_p))
+                    if rank.value != _lib.RANK_NEEDS_OMEGA:
+                        break
+                    omega = pending.result() if pending is not None else draw()
+                    pending = None
+                    dev_omega = self._upload(np.asfortranarray(omega).T)      # the transpose's C order = column-major omega
+            finally:
+                if pending is not None:
+                    pending.result()          # the caller's generator must have moved on before anyone else draws
             self.split_counts["randomized"] += 1
         else:
             s = np.empty(full, dtype=np.float64)
