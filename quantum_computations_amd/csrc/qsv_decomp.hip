@@ -628,6 +628,154 @@ int wide_factor_svd(hipStream_t stream, const amp_t *R, int l, amp_t *W, amp_t *
     return QSV_OK;
 }
 
+// ---- one-sided Jacobi SVD of a whole matrix: the exact split of a theta that is NOT numerically low-rank ---------------
+// X (column-major L x k, k <= L, k <= JACOBI_MAX_COLUMNS) holds the k shorter vectors of theta; X J = Q S with J unitary
+// (k x k) and orthogonal columns Q S.  A workgroup per column pair and launch per tournament step, as the wide factor above,
+// but with 256 threads per pair (columns are thousands of entries long) -- rocSOLVER's zgesvd needs 1.35 s for a
+// 1200 x 1200 matrix of rank 700 and 5 s at 2000 x 2000 (bdsqr launch storms); these sweeps take a fifth of that.
+constexpr int JACOBI_MAX_COLUMNS = 2048;
+
+// squared norms of the k columns of an L x k matrix, element (r, c) at src[r * stride_row + c * stride_col]
+__global__ __launch_bounds__(256) void k_column_norms(const amp_t *__restrict__ src, uint64_t stride_row, uint64_t stride_col,
+                                                     uint64_t L, double *__restrict__ norms) {
+    __shared__ double red[4];
+    const amp_t *col = src + static_cast<uint64_t>(blockIdx.x) * stride_col;
+    double s = 0.0;
+    for (uint64_t r = threadIdx.x; r < L; r += 256) {
+        const amp_t v = col[r * stride_row];
+        s += v.x * v.x + v.y * v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) norms[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// W[:, c] = source column order[c]; the source is either column-major (L x k: stride_row = 1, stride_col = L) or the
+// row-major (L x k) matrix (stride_row = k, stride_col = 1).  J = that permutation, so that X J = W holds for the source X.
+__global__ __launch_bounds__(256) void k_jacobi_gather(const amp_t *__restrict__ src, uint64_t stride_row, uint64_t stride_col,
+                                                      const int *__restrict__ order, amp_t *__restrict__ W,
+                                                      amp_t *__restrict__ J, uint64_t L, int k) {
+    const uint64_t total = L * static_cast<uint64_t>(k);
+    for (uint64_t o = blockIdx.x * 256ull + threadIdx.x; o < total; o += gridDim.x * 256ull) {
+        const uint64_t r = o % L, c = o / L;
+        W[o] = src[r * stride_row + static_cast<uint64_t>(order[c]) * stride_col];
+    }
+    const uint64_t kk = static_cast<uint64_t>(k) * k;
+    for (uint64_t o = blockIdx.x * 256ull + threadIdx.x; o < kk; o += gridDim.x * 256ull)
+        J[o] = amp_t{static_cast<int>(o % k) == order[o / k] ? 1.0 : 0.0, 0.0};      // column-major: row o % k, column o / k
+}
+
+// J (column-major k x k) = the conjugate transpose of the column-major k x k matrix `vh`
+__global__ __launch_bounds__(256) void k_jacobi_seed(const amp_t *__restrict__ vh, amp_t *__restrict__ J, int k) {
+    const uint64_t kk = static_cast<uint64_t>(k) * k;
+    for (uint64_t o = blockIdx.x * 256ull + threadIdx.x; o < kk; o += gridDim.x * 256ull) {
+        const uint64_t i = o % k, c = o / k;
+        const amp_t v = vh[c + i * k];
+        J[o] = amp_t{v.x, -v.y};
+    }
+}
+
+// `floor2`: squared norm below which a column counts as numerically zero (see jacobi_full_split) and sits out
+__global__ __launch_bounds__(256) void k_jacobi_pair(amp_t *__restrict__ W, amp_t *__restrict__ J, uint64_t L, int k, int kp,
+                                                    int step, double floor2, int *__restrict__ rotated) {
+    __shared__ double red[4][4];
+    const int pair = blockIdx.x, t = threadIdx.x;
+    int p, q;
+    if (pair == 0) {
+        p = kp - 1;
+        q = step;
+    } else {
+        p = (step + pair) % (kp - 1);
+        q = (step - pair + (kp - 1)) % (kp - 1);
+    }
+    if (p > q) {
+        const int tmp = p;
+        p = q;
+        q = tmp;
+    }
+    if (q >= k) return;       // the padding column of an odd k sits out
+    amp_t *wp = W + static_cast<uint64_t>(p) * L, *wq = W + static_cast<uint64_t>(q) * L;
+    double alpha = 0.0, beta = 0.0;
+    amp_t gamma = {0.0, 0.0};
+    for (uint64_t r = t; r < L; r += 256) {
+        const amp_t x = wp[r], y = wq[r];
+        alpha += x.x * x.x + x.y * x.y;
+        beta += y.x * y.x + y.y * y.y;
+        const amp_t g = conj_mul(x, y);
+        gamma.x += g.x;
+        gamma.y += g.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        alpha += __shfl_xor(alpha, o, 64);
+        beta += __shfl_xor(beta, o, 64);
+        gamma.x += __shfl_xor(gamma.x, o, 64);
+        gamma.y += __shfl_xor(gamma.y, o, 64);
+    }
+    if ((t & 63) == 0) {
+        red[t >> 6][0] = alpha;
+        red[t >> 6][1] = beta;
+        red[t >> 6][2] = gamma.x;
+        red[t >> 6][3] = gamma.y;
+    }
+    __syncthreads();
+    alpha = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    beta = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    gamma.x = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
+    gamma.y = (red[0][3] + red[1][3]) + (red[2][3] + red[3][3]);
+    // orthogonal to the rounding level of an L-term inner product, sqrt(L) eps (LAPACK's zgesvj uses the same tolerance):
+    // below it the computed gamma is noise and the sweeps would never end
+    const double eps = 2.220446049250313e-16, g2 = gamma.x * gamma.x + gamma.y * gamma.y;
+    if (!(g2 > static_cast<double>(L) * eps * eps * alpha * beta) || !(g2 > 0.0)) return;      // every thread holds the same sums
+    if (!(alpha > floor2) || !(beta > floor2)) return;
+    const double g = sqrt(g2);
+    const amp_t phase = {gamma.x / g, -gamma.y / g};
+    const double zeta = (beta - alpha) / (2.0 * g);
+    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + tt * tt), sn = c * tt;
+    for (uint64_t r = t; r < L; r += 256) {
+        const amp_t x = wp[r], y = plain_mul(wq[r], phase);
+        wp[r] = amp_t{c * x.x - sn * y.x, c * x.y - sn * y.y};
+        wq[r] = amp_t{sn * x.x + c * y.x, sn * x.y + c * y.y};
+    }
+    amp_t *jp = J + static_cast<uint64_t>(p) * k, *jq = J + static_cast<uint64_t>(q) * k;
+    for (int r = t; r < k; r += 256) {
+        const amp_t x = jp[r], y = plain_mul(jq[r], phase);
+        jp[r] = amp_t{c * x.x - sn * y.x, c * x.y - sn * y.y};
+        jq[r] = amp_t{sn * x.x + c * y.x, sn * x.y + c * y.y};
+    }
+    if (t == 0) *rotated = 1;
+}
+
+// The two factors of the split from the converged sweeps: `order[a]` = working column of the a-th largest value,
+// sigma2 = squared column norms.  long_side[x, a] = W[x, order[a]] / sigma_a^(1/2) (the unit vector times sqrt(sigma)),
+// short_side[i, a] = J[i, order[a]] * sigma_a^(1/2), either side conjugated on request.  Both are written into row-major
+// (rows x r) / (r x cols) outputs through (stride_x, stride_a).
+__global__ __launch_bounds__(256) void k_jacobi_factors(const amp_t *__restrict__ W, const amp_t *__restrict__ J,
+                                                       const int *__restrict__ order, const double *__restrict__ sigma2,
+                                                       uint64_t L, int k, uint64_t r, amp_t *__restrict__ long_out,
+                                                       uint64_t long_sx, uint64_t long_sa, amp_t *__restrict__ short_out,
+                                                       uint64_t short_si, uint64_t short_sa, int conj_long, int conj_short) {
+    const uint64_t n_long = L * r, n_short = static_cast<uint64_t>(k) * r;
+    for (uint64_t o = blockIdx.x * 256ull + threadIdx.x; o < n_long + n_short; o += gridDim.x * 256ull) {
+        if (o < n_long) {
+            const uint64_t x = o % L, a = o / L;
+            const int c = order[a];
+            const double sigma = sqrt(sigma2[c]), w = sigma > 0.0 ? 1.0 / sqrt(sigma) : 0.0;
+            const amp_t v = W[static_cast<uint64_t>(c) * L + x];
+            long_out[x * long_sx + a * long_sa] = amp_t{v.x * w, conj_long ? -v.y * w : v.y * w};
+        } else {
+            const uint64_t e = o - n_long, i = e % k, a = e / k;
+            const int c = order[a];
+            const double w = sqrt(sqrt(sigma2[c]));
+            const amp_t v = J[static_cast<uint64_t>(c) * k + i];
+            short_out[i * short_si + a * short_sa] = amp_t{v.x * w, conj_short ? -v.y * w : v.y * w};
+        }
+    }
+}
+
 // out[a, b] (row-major A x B) = sqrt(s[by_row ? a : b]) * (conj ? conj(in[...]) : in[a * sa + b * sb])
 __global__ __launch_bounds__(QSV_BLOCK) void k_scale_strided_conj(const amp_t *__restrict__ in, amp_t *__restrict__ out,
                                                                  uint64_t A, uint64_t B, uint64_t sa, uint64_t sb,
@@ -677,6 +825,142 @@ int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream
                           amp_t *m2, uint64_t capacity, uint64_t *rank_out, std::vector<double> *values,
                           double *frobenius_squared_out = nullptr);
 
+// The exact split by one-sided Jacobi sweeps over the whole matrix (k_jacobi_pair): theta is left untouched;
+// QSV_UNDECIDED when the matrix is outside what the sweeps take or they did not converge (the library SVD decides then).
+//
+// Started from the columns themselves the sweeps crawl on graded matrices (25 sweeps at 120 x 120 with singular values over
+// six decades, 40+ at 1200 x 1200).  `seed_u` / `seed_vh` != null: the factors of rocSOLVER's zgesdd of theta^T (column-major
+// cols x k and k x rows) -- through the eigenvectors of A^H A, good to ~1e-8 sigma_max, useless as an answer under a tight
+// tolerance but an excellent preconditioner: X J0 with J0 the seed's unitary factor has nearly orthogonal columns, and the
+// sweeps only polish (X J = W holds to rounding whatever the seed is, because W is recomputed as the product).
+int jacobi_full_split(RocblasApi &a, rocblas_handle h, hipStream_t stream, const amp_t *theta, uint64_t rows, uint64_t cols,
+                      int64_t max_bond_dim, double abs_err, double rel_err, amp_t *m1, amp_t *m2, uint64_t capacity,
+                      uint64_t *rank_out, double *s_host, DeviceBuffers &buf, const amp_t *seed_u, const amp_t *seed_vh) {
+    const bool wide = rows <= cols;          // the k shorter vectors: rows of theta (contiguous) or its columns
+    const uint64_t k64 = wide ? rows : cols, L = wide ? cols : rows;
+    if (k64 < 2 || k64 > static_cast<uint64_t>(JACOBI_MAX_COLUMNS)) return QSV_UNDECIDED;
+    const int k = static_cast<int>(k64), kp = (k + 1) & ~1;
+    const bool seeded = seed_u && seed_vh && a.zgemm;
+    amp_t *W = nullptr, *J = nullptr;      // from the caller's workspace (its reservation counts them in)
+    double *norms = nullptr;
+    int *order = nullptr, *flag = nullptr;
+    if (!buf.alloc(&W, sizeof(amp_t) * L * k64) || !buf.alloc(&J, sizeof(amp_t) * k64 * k64) ||
+        !buf.alloc(&norms, sizeof(double) * k64) || !buf.alloc(&order, sizeof(int) * k64) || !buf.alloc(&flag, sizeof(int)))
+        return QSV_UNDECIDED;
+    std::vector<double> host_norms(k);
+    std::vector<int> host_order(k);
+    auto sorted_by_norm = [&]() -> int {      // host_order[a] = column with the a-th largest norm
+        QSV_HIP(hipMemcpyAsync(host_norms.data(), norms, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+        QSV_HIP(hipStreamSynchronize(stream));
+        for (int c = 0; c < k; ++c) host_order[c] = c;
+        std::stable_sort(host_order.begin(), host_order.end(), [&](int x, int y) { return host_norms[x] > host_norms[y]; });
+        QSV_HIP(hipMemcpyAsync(order, host_order.data(), sizeof(int) * k, hipMemcpyHostToDevice, stream));
+        QSV_HIP(hipStreamSynchronize(stream));    // host_order is reused
+        return QSV_OK;
+    };
+    // The working matrix: X (L x k) with X[x, c] = theta[c, x] (wide) or theta[x, c] (tall) -- or, seeded and tall, conj(X),
+    // whose product with the seed is a plain library GEMM (M = theta^T is what the buffer holds column-major):
+    //   wide:  M = U' S V'^H  ->  X = M,          J0 = V' = (seed_vh)^H,  W = M (seed_vh)^H
+    //   tall:  M^H = V' S U'^H ->  conj(X) = M^H,  J0 = U' = seed_u,       W = M^H seed_u
+    const bool conj_work = seeded && !wide;
+    int rc;
+    if (seeded) {
+        const rocblas_double_complex one{1.0, 0.0}, zero{0.0, 0.0};
+        auto Z = [](const amp_t *p) { return reinterpret_cast<const rocblas_double_complex *>(p); };
+        const rocblas_int Li = static_cast<rocblas_int>(L);
+        rocblas_status st;
+        if (wide) {
+            hipLaunchKernelGGL(k_jacobi_seed, dim3(1024), dim3(256), 0, stream, seed_vh, J, k);
+            st = a.zgemm(h, rocblas_operation_none, rocblas_operation_conjugate_transpose, Li, k, k, &one, Z(theta), Li, 0,
+                         Z(seed_vh), k, 0, &zero, reinterpret_cast<rocblas_double_complex *>(W), Li, 0, 1);
+        } else {
+            QSV_HIP(hipMemcpyAsync(J, seed_u, sizeof(amp_t) * k64 * k64, hipMemcpyDeviceToDevice, stream));
+            st = a.zgemm(h, rocblas_operation_conjugate_transpose, rocblas_operation_none, Li, k, k, &one, Z(theta), k, 0,
+                         Z(seed_u), k, 0, &zero, reinterpret_cast<rocblas_double_complex *>(W), Li, 0, 1);
+        }
+        if (st != rocblas_status_success) return QSV_UNDECIDED;
+        QSV_HIP(hipGetLastError());
+    } else {
+        // element (x, c) of X: wide theta -> theta[c, x] (buffer read column-major with ld cols); tall theta -> theta[x, c];
+        // columns in decreasing norm first (de Rijk)
+        const uint64_t stride_row = wide ? 1 : cols, stride_col = wide ? cols : 1;
+        hipLaunchKernelGGL(k_column_norms, dim3(k), dim3(256), 0, stream, theta, stride_row, stride_col, L, norms);
+        QSV_HIP(hipGetLastError());
+        rc = sorted_by_norm();
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_jacobi_gather, dim3(1024), dim3(256), 0, stream, theta, stride_row, stride_col, order, W, J, L, k);
+    }
+    // Columns of norm below 4 sqrt(L) eps ||X||_F are rounding dust (the product X J itself is only that accurate): their
+    // singular values are numerically zero -- LAPACK returns noise of that size for them too -- and mutually orthogonal
+    // dust is not worth sweeps that never end (rotations among the large columns keep re-randomising it).  X = W J^H holds
+    // whether or not they are orthogonal, so the product of the two factors is unaffected.
+    hipLaunchKernelGGL(k_column_norms, dim3(k), dim3(256), 0, stream, W, static_cast<uint64_t>(1), L, L, norms);
+    QSV_HIP(hipGetLastError());
+    QSV_HIP(hipMemcpyAsync(host_norms.data(), norms, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+    QSV_HIP(hipStreamSynchronize(stream));
+    double frobenius2 = 0.0;
+    for (double v : host_norms) frobenius2 += v;
+    const double floor2 = 16.0 * static_cast<double>(L) * 4.930380657631324e-32 * frobenius2;
+    bool converged = false;
+    static const bool trace = std::getenv("QSV_TRACE_SPLIT") != nullptr;
+    const int max_sweeps = seeded ? 24 : 40;       // a seeded run that needs more is not being helped by its seed
+    int sweeps = 0;
+    for (; sweeps < max_sweeps && !converged; ++sweeps) {
+        QSV_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream));
+        for (int step = 0; step < kp - 1; ++step)
+            hipLaunchKernelGGL(k_jacobi_pair, dim3(kp / 2), dim3(256), 0, stream, W, J, L, k, kp, step, floor2, flag);
+        QSV_HIP(hipGetLastError());
+        int rotated = 0;
+        QSV_HIP(hipMemcpyAsync(&rotated, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+        QSV_HIP(hipStreamSynchronize(stream));
+        converged = !rotated;
+    }
+    if (trace)
+        fprintf(stderr, "[qsv split] %llu x %llu: %sJacobi sweeps over the whole matrix: %d%s\n",
+                static_cast<unsigned long long>(rows), static_cast<unsigned long long>(cols), seeded ? "seeded " : "", sweeps,
+                converged ? "" : " (not converged)");
+    if (!converged) return QSV_UNDECIDED;
+    hipLaunchKernelGGL(k_column_norms, dim3(k), dim3(256), 0, stream, W, static_cast<uint64_t>(1), L, L, norms);
+    QSV_HIP(hipGetLastError());
+    rc = sorted_by_norm();
+    if (rc) return rc;
+    std::vector<double> sv(k);
+    for (int c = 0; c < k; ++c) sv[c] = sqrt(host_norms[host_order[c]]);
+    // The norm of a dust column is the rounding error of the product X J (hundreds of eps sigma_max), not a singular value;
+    // a backward-stable SVD reports eps sigma_max-sized values there, and a tail of 500 such columns must not reach a tight
+    // truncation threshold.  Dust is relabelled to at most eps sigma_max: if the rule keeps such a column anyway
+    // (rel_err = abs_err = 0) its outer product W[:, c] J[:, c]^H enters the factors unchanged -- sigma only decides how
+    // the two factors share it.
+    bool relabelled = false;
+    for (int c = 0; c < k; ++c)
+        if (!(host_norms[host_order[c]] > floor2)) {
+            const double label = std::min(sv[c], 2.220446049250313e-16 * sv[0]);
+            sv[c] = label;
+            host_norms[host_order[c]] = label * label;
+            relabelled = true;
+        }
+    if (relabelled) {
+        QSV_HIP(hipMemcpyAsync(norms, host_norms.data(), sizeof(double) * k, hipMemcpyHostToDevice, stream));
+        QSV_HIP(hipStreamSynchronize(stream));
+    }
+    const uint64_t r = kept_rank(sv, max_bond_dim, abs_err, rel_err);
+    if (r > capacity) return qsv_fail(QSV_EINVAL, "output buffers are smaller than the kept bond dimension");
+    if (r > 0) {
+        // X = W J^H (or its conjugate).  wide: theta = X^T: m2 (r x cols) takes the long vectors, m1 (rows x r) the rotations;
+        // tall: theta = X: the other way round
+        amp_t *long_out = wide ? m2 : m1, *short_out = wide ? m1 : m2;
+        const uint64_t long_sx = wide ? 1 : r, long_sa = wide ? cols : 1, short_si = wide ? r : 1, short_sa = wide ? 1 : cols;
+        hipLaunchKernelGGL(k_jacobi_factors, dim3(1024), dim3(256), 0, stream, W, J, order, norms, L, k, r, long_out, long_sx,
+                           long_sa, short_out, short_si, short_sa, conj_work ? 1 : 0, conj_work ? 0 : 1);
+        QSV_HIP(hipGetLastError());
+    }
+    QSV_HIP(hipStreamSynchronize(stream));   // the workspace is freed on return
+    if (s_host)
+        for (int c = 0; c < k; ++c) s_host[c] = sv[c];
+    *rank_out = r;
+    return QSV_OK;
+}
+
 // tensor_svd (cv_simulator/mps.py:52-97) of a row-major (rows x cols) device matrix:
 //   theta = U S Vh,  r from the truncation rule,  m1 = U[:, :r] sqrt(S[:r]),  m2 = sqrt(S[:r]) Vh[:r, :].
 // rocSOLVER is column-major, so it factors theta^T = U' S V'^H (cols x rows); then U = (V'^H)^T and Vh = U'^T, i.e.
@@ -710,7 +994,7 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
         if (fast != QSV_UNDECIDED) return fast;
     }
     DeviceBuffers buf;
-    buf.reserve(device, sizeof(amp_t) * (cols * k + k * rows + rows * cols) + 16 * k + 8192);
+    buf.reserve(device, sizeof(amp_t) * (cols * k + k * rows + 2 * rows * cols + k * k) + 32 * k + 16384);   // + the Jacobi route's copy
     double *dS = nullptr, *dE = nullptr;
     amp_t *dU = nullptr, *dV = nullptr;
     rocblas_int *dinfo = nullptr;
@@ -743,7 +1027,16 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
         const double norm = sqrt(frobenius_squared);
         hopeless = (abs_err > rel_err * norm ? abs_err : rel_err * norm) < 1e-5 * norm;
     }
-    if (a.zgesdd && gram_route_enabled && !hopeless && (rel_err >= 1e-6 || abs_err > 0.0)) {
+    static const bool jacobi_enabled = [] {
+        const char *v = std::getenv("QSV_SVD");
+        return !(v && (std::string(v) == "exact" || std::string(v) == "library"));
+    }();
+    // zgesdd's answer is tried as it is only when the tolerance cannot tell the difference; under a tight one its factors
+    // still seed the Jacobi sweeps over the whole matrix (jacobi_full_split), which then need a handful of sweeps
+    const bool loose = !hopeless && (rel_err >= 1e-6 || abs_err > 0.0);
+    const bool jacobi_fits = jacobi_enabled && k >= 2 && k <= static_cast<uint64_t>(JACOBI_MAX_COLUMNS);
+    bool have_seed = false;
+    if (a.zgesdd && gram_route_enabled && (loose || jacobi_fits)) {
         amp_t *backup = nullptr;
         if (buf.alloc(&backup, sizeof(amp_t) * rows * cols)) {
             QSV_HIP(hipMemcpyAsync(backup, theta, sizeof(amp_t) * rows * cols, hipMemcpyDeviceToDevice, stream));
@@ -751,7 +1044,8 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
                          dinfo) == rocblas_status_success) {
                 const int rc_fetch = fetch_values();
                 if (rc_fetch) return rc_fetch;
-                if (info == 0 && k > 0) {
+                have_seed = info == 0;
+                if (info == 0 && k > 0 && loose) {
                     const double floor_value = 2e-8 * sv[0], margin = floor_value * static_cast<double>(k);
                     const double allowed = allowed_error(sv, abs_err, rel_err);
                     if (allowed > 100.0 * margin) {
@@ -763,6 +1057,11 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
             }
             if (!decided) QSV_HIP(hipMemcpyAsync(theta, backup, sizeof(amp_t) * rows * cols, hipMemcpyDeviceToDevice, stream));
         }
+    }
+    if (!decided && jacobi_fits) {      // theta is intact here (zgesdd worked on it, but it was restored)
+        const int own = jacobi_full_split(a, h, stream, theta, rows, cols, max_bond_dim, abs_err, rel_err, m1, m2, capacity,
+                                          rank_out, s_host, buf, have_seed ? dU : nullptr, have_seed ? dV : nullptr);
+        if (own != QSV_UNDECIDED) return own;
     }
     if (!decided) {
         const rocblas_status s = a.zgesvd(h, rocblas_svect_singular, rocblas_svect_singular, ci, ri, Zp(theta), ci, dS, Zp(dU),

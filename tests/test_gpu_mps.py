@@ -220,5 +220,43 @@ def test_exact_split_at_the_default_tolerance(rows, cols, rank, decay):
     got = np.tensordot(m1, m2, axes=1).reshape(rows, cols)
     assert maxdiff(got, want1 @ want2) < 1e-11
     print(f"split {rows}x{cols} rank {rank}: {seconds * 1e3:.1f} ms")
-    if rank <= 230:
-        assert seconds < 2.0, seconds                # tens of milliseconds; rocSOLVER's zgesvd takes 1-14 s on these
+    # tens of milliseconds through the verified low-rank route, ~0.2 s through the Jacobi sweeps over the whole matrix
+    # (rank 700 does not fit 256 probes); rocSOLVER's zgesvd takes 1-14 s on these
+    assert seconds < (2.0 if rank <= 230 else 1.0), seconds
+
+
+@pytest.mark.parametrize("rows,cols", [(35, 7), (61, 61), (120, 333), (333, 120), (401, 400), (640, 900)])
+@pytest.mark.parametrize("options", [{}, {"rel_err": 0.0}, {"max_bond_dim": "a third"}, {"rel_err": 1e-7, "abs_err": 1e-9}])
+def test_exact_split_of_full_rank_matrices(rows, cols, options):
+    """Round 3: a theta that is NOT numerically low-rank takes one-sided Jacobi sweeps over the whole matrix, seeded with
+    the factors of rocSOLVER's Gram-based ``zgesdd`` (``jacobi_full_split`` in csrc/qsv_decomp.hip) -- tall, wide, square
+    and odd sizes, spectra graded over eight decades with rounding dust below, every truncation option: the kept rank
+    must be the one the rule gives on LAPACK's spectrum, the singular values must agree with LAPACK's, and the product
+    must match the exactly truncated one."""
+    from oracle import mps_oracle as MO
+    rng = np.random.default_rng(rows * 1000 + cols)
+    full = min(rows, cols)
+    if "max_bond_dim" in options:
+        options = {"max_bond_dim": full // 3 + 1}          # a cap that keeps tensor_svd on its exact branch (cap * 10 >= full)
+    u, _ = np.linalg.qr(rng.standard_normal((rows, full)) + 1j * rng.standard_normal((rows, full)))
+    v, _ = np.linalg.qr(rng.standard_normal((cols, full)) + 1j * rng.standard_normal((cols, full)))
+    spectrum = np.exp(-18.0 * np.arange(full) / full)
+    dust = full // 5
+    if dust:
+        spectrum[-dust:] = 1e-17 * rng.random(dust)
+    a = (u * spectrum) @ v.conj().T
+    want1, want2 = MO.split(a, **options)
+    m1, m2 = tensor_svd(a.reshape(rows, 1, 1, cols), [0, 1], [2, 3], **options)
+    if options.get("rel_err", 1.0) == 0.0 and "abs_err" not in options:
+        # nothing may be truncated: LAPACK keeps every value above exactly zero, dust included
+        assert m1.shape[-1] == want1.shape[1] == full
+    else:
+        assert m1.shape[-1] == want1.shape[1], (m1.shape[-1], want1.shape[1])
+    got = np.tensordot(m1, m2, axes=1).reshape(rows, cols)
+    assert maxdiff(got, want1 @ want2) < 1e-13
+    # the factors carry sqrt(S) each: column norms of m1 squared are the singular values
+    kept = m1.shape[-1]
+    values = np.sum(np.abs(m1.reshape(rows, kept)) ** 2, axis=0)
+    lapack = np.linalg.svd(a, compute_uv=False)[:kept]
+    resolved = lapack > 1e-12
+    assert np.max(np.abs(values[resolved] - lapack[resolved]) / lapack[resolved]) < 1e-9
