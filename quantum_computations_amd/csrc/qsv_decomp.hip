@@ -396,9 +396,17 @@ __global__ __launch_bounds__(256) void k_panel_solve(amp_t *__restrict__ Y, uint
 // SVD of the l x l matrix R (row-major) by one-sided Jacobi in one workgroup: R V = U S.  Column pairs follow a
 // round-robin tournament (l/2 disjoint pairs per step, a few threads per pair); outputs are sorted by decreasing
 // singular value: U, V column-major (l x l), S (l doubles).
-// (1024 threads: 16 per column pair at l = 64 -- a team then reads 256 contiguous bytes of a column, one conflict-free LDS
-// pass, where the 8-thread teams of a 256-thread workgroup collided two by two -- and four rows per thread per rotation)
-constexpr int SVD_THREADS = 1024;
+// (Measured on the GKP Grover run, 64 x 64 factors: 830 us per launch with 256 threads -- 8 per column pair --, 800 with
+// 512 and 1060 with 1024: the 63 workgroup barriers per sweep cost more with every wave added.  QSV_SVD_THREADS switches.)
+constexpr int SVD_THREADS = 1024;     // launch bound; the launch uses small_svd_threads()
+static int small_svd_threads() {
+    static const int v = [] {
+        const char *e = std::getenv("QSV_SVD_THREADS");
+        const int n = e ? atoi(e) : 256;
+        return n == 512 || n == 1024 ? n : 256;
+    }();
+    return v;
+}
 __global__ __launch_bounds__(SVD_THREADS) void k_small_svd(const amp_t *__restrict__ R, int l, amp_t *__restrict__ U,
                                                   double *__restrict__ S, amp_t *__restrict__ V) {
     __shared__ amp_t W[LMAX * LMAX];    // working columns, column-major
@@ -406,8 +414,8 @@ __global__ __launch_bounds__(SVD_THREADS) void k_small_svd(const amp_t *__restri
     __shared__ double sigma[LMAX];
     __shared__ int order[LMAX];
     __shared__ int rotated;
-    const int t = threadIdx.x;
-    for (int e = t; e < l * l; e += SVD_THREADS) {
+    const int t = threadIdx.x, NT = blockDim.x;
+    for (int e = t; e < l * l; e += NT) {
         const int c = e / l, r = e % l;
         // the working matrix is R^H: its columns are the conjugated rows of the upper triangle, which the one-sided sweeps
         // orthogonalise in fewer passes than the columns of R itself (the triangle's rows are already nearly graded);
@@ -417,8 +425,8 @@ __global__ __launch_bounds__(SVD_THREADS) void k_small_svd(const amp_t *__restri
         Vw[c * l + r] = amp_t{r == c ? 1.0 : 0.0, 0.0};
     }
     const int lp = (l + 1) & ~1, pairs = lp / 2;
-    int team = 1;                       // threads per pair: a power of two, pairs * team <= SVD_THREADS, team <= 64
-    while (team * 2 * pairs <= SVD_THREADS && team < 64) team *= 2;
+    int team = 1;                       // threads per pair: a power of two, pairs * team <= blockDim.x, team <= 64
+    while (team * 2 * pairs <= NT && team < 64) team *= 2;
     const int pair = t / team, member = t % team;
     const double eps = 2.220446049250313e-16;
     for (int sweep = 0; sweep < 40; ++sweep) {
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(SVD_THREADS) void k_small_svd(const amp_t *__restri
         if (!rotated) break;
     }
     __syncthreads();
-    for (int c = t; c < l; c += SVD_THREADS) {
+    for (int c = t; c < l; c += NT) {
         double s = 0.0;
         for (int r = 0; r < l; ++r) s += W[c * l + r].x * W[c * l + r].x + W[c * l + r].y * W[c * l + r].y;
         sigma[c] = sqrt(s);
@@ -496,14 +504,14 @@ __global__ __launch_bounds__(SVD_THREADS) void k_small_svd(const amp_t *__restri
         }
     }
     __syncthreads();
-    for (int e = t; e < l * l; e += SVD_THREADS) {
+    for (int e = t; e < l * l; e += NT) {
         const int rank = e / l, r = e % l, c = order[rank];
         const double s = sigma[c];
         const amp_t w = W[c * l + r];
         U[rank * l + r] = s > 0.0 ? amp_t{w.x / s, w.y / s} : amp_t{0.0, 0.0};
         V[rank * l + r] = Vw[c * l + r];
     }
-    for (int rank = t; rank < l; rank += SVD_THREADS) S[rank] = sigma[order[rank]];
+    for (int rank = t; rank < l; rank += NT) S[rank] = sigma[order[rank]];
 }
 
 // ---- the same one-sided Jacobi SVD for factors wider than 64 columns (up to WIDE_FACTOR): the working matrices live in
@@ -1729,7 +1737,7 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
     if (!ok) return qsv_fail(QSV_EHIP, "rocBLAS call failed in the randomized range finder");
     if (rc) return rc;
     if (L <= LMAX) {
-        hipLaunchKernelGGL(k_small_svd, dim3(1), dim3(SVD_THREADS), 0, stream, r_total, l, Vr, dS, Ur);   // decomposes R^H: roles swap
+        hipLaunchKernelGGL(k_small_svd, dim3(1), dim3(small_svd_threads()), 0, stream, r_total, l, Vr, dS, Ur);   // decomposes R^H: roles swap
         QSV_HIP(hipGetLastError());
     } else {
         // wider than the one-workgroup Jacobi kernel: the same sweeps with the working matrices in global memory, one

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end measurement session on the GPU box: everything the committed summaries under profiles/ are made from.
-#   gpurun --timeout 1200 -- 'bash tools/final_profiles.sh [part]'      part = bench | sweeps | all (default)
+#   gpurun --timeout 1200 -- 'bash tools/final_profiles.sh [part]'      part = bench | sweeps | gkp | all (default)
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
@@ -43,6 +43,13 @@ python3 $R/tools/probe_tile_12.py 28 --pairs > $O/tile12_n28_pairs.txt 2>&1
 python3 $R/tools/probe_fused_blocks.py 5 > $O/fused_blocks_k5.txt 2>&1
 python3 $R/tools/bench_gkp.py --circuit grover27 --bond 100 --rel-err 1e-2 --out $O/gkp_grover.json > $O/gkp_grover.log 2>&1
 echo "sweeps done"
+fi
+if [ "$PART" = gkp ] || [ "$PART" = all ]; then
+python3 $R/tools/bench_gkp.py --circuit grover27 --bond 100 --rel-err 1e-2 --out $O/gkp_grover.json > $O/gkp_grover.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/gkp_stats -o gkp -- python3 $R/tools/bench_gkp.py --circuit grover27 --bond 100 --rel-err 1e-2 > $O/gkp_stats.log 2>&1
+python3 $R/tools/probe_exact_split.py > $O/exact_split.txt 2>&1
+python3 $R/tools/probe_sequence.py 30 3 > $O/sequence_blocks.txt 2>&1
+echo "gkp done"
 fi
 # keep only the small summaries of the profiler directories (the traces are hundreds of MiB)
 find $O -name "*.csv" -size +8M -delete
