@@ -592,7 +592,7 @@ def main():
         # scheduler of Simulator(fuse=k) (quantum_computations_amd/fusion.py) -- fewer, denser launches.
         from quantum_computations_amd.fusion import fuse_circuit, fusion_stats
         result["with_gate_fusion"] = {}
-        for k in (3, 4, 5):
+        for k in (3, 4, 5, 6):
             fused = fuse_circuit(gates, k, n_qubits=n)
             for gate in fused:
                 gate.apply(dev)
