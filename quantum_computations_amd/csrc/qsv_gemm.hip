@@ -99,10 +99,49 @@ using namespace qsvl;
 // C (m x n) = op(A) . op(B) on row-major complex128 device buffers with tight leading dimensions.
 // Row-major C = op(A) op(B) is the column-major product C^T = op(B)^T op(A)^T, and a row-major buffer read as
 // column-major IS the transpose, so the operands swap places and keep their op flags.
+// A handful of output entries over a long inner dimension -- the environment matrices of the MPS read-out
+// (site_register.py: (chi x chi) = X^H T with chi = 1..2 and an inner dimension of chi d = 1000..4000): rocBLAS runs such a
+// product as ONE 64 x 64 macro tile walking the whole inner dimension (170-210 us each, 0.15 s of the GKP Grover run).
+// Here every output entry is a workgroup-wide reduction; the sum over p is taken in a fixed order.
+__global__ __launch_bounds__(256) void k_gemm_few_outputs(const amp_t *__restrict__ A, const amp_t *__restrict__ B,
+                                                         amp_t *__restrict__ C, int op_a, int op_b, uint64_t m, uint64_t n,
+                                                         uint64_t k) {
+    __shared__ double red[4][2];
+    const uint64_t i = blockIdx.x / n, j = blockIdx.x % n;
+    double re = 0.0, im = 0.0;
+    for (uint64_t p = threadIdx.x; p < k; p += 256) {
+        amp_t x = op_a == 0 ? A[i * k + p] : A[p * m + i];
+        amp_t y = op_b == 0 ? B[p * n + j] : B[j * k + p];
+        if (op_a == 2) x.y = -x.y;
+        if (op_b == 2) y.y = -y.y;
+        re += x.x * y.x - x.y * y.y;
+        im += x.x * y.y + x.y * y.x;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        re += __shfl_xor(re, o, 64);
+        im += __shfl_xor(im, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6][0] = re;
+        red[threadIdx.x >> 6][1] = im;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        C[blockIdx.x] = amp_t{(red[0][0] + red[1][0]) + (red[2][0] + red[3][0]), (red[0][1] + red[1][1]) + (red[2][1] + red[3][1])};
+}
+
 int qsvg_gemm(int device, hipStream_t stream, int op_a, int op_b, uint64_t m, uint64_t n, uint64_t k,
               const amp_t *a_ptr, const amp_t *b_ptr, amp_t *c_ptr) {
     const uint64_t lim = 0x7fffffffull;
     if (m > lim || n > lim || k > lim) return qsv_fail(QSV_EINVAL, "matrix dimension exceeds 2^31 - 1");
+    if (m * n <= 64 && k >= 256 && m > 0 && n > 0) {
+        QSV_HIP(hipSetDevice(device));
+        hipLaunchKernelGGL(k_gemm_few_outputs, dim3(static_cast<unsigned>(m * n)), dim3(256), 0, stream, a_ptr, b_ptr, c_ptr,
+                           op_a, op_b, m, n, k);
+        QSV_HIP(hipGetLastError());
+        return QSV_OK;
+    }
     RocblasApi &a = api();
     std::lock_guard<std::mutex> guard(a.lock);
     int rc;

@@ -153,6 +153,34 @@ def test_mfma_tall_skinny_products(n, m, l):
                   C.c_void_p(dev_a.data_ptr()), C.c_void_p(dev_a.data_ptr()))
 
 
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1000), (2, 2, 2000), (1, 7, 333), (8, 8, 4097), (3, 2, 256), (2, 2, 255), (9, 9, 500)])
+def test_tensor_gemm_with_few_outputs_and_a_long_inner_dimension(m, n, k):
+    """``qsv_tensor_gemm`` on the shapes of the MPS environment matrices (``site_register.py``: chi x chi outputs over an
+    inner dimension of chi d): at most 64 outputs over k >= 256 take the reduction kernel ``k_gemm_few_outputs``, the
+    others rocBLAS -- every combination of plain / transposed / conjugate-transposed operands against NumPy."""
+    import ctypes as C
+
+    import torch
+
+    from quantum_computations_amd import _lib
+    rng = np.random.default_rng(m * 100 + n * 10 + k)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    form = {0: lambda x: x, 1: lambda x: x.T, 2: lambda x: x.conj().T}
+    for op_a in (0, 1, 2):
+        for op_b in (0, 1, 2):
+            shape_a = (m, k) if op_a == 0 else (k, m)
+            shape_b = (k, n) if op_b == 0 else (n, k)
+            a = rng.standard_normal(shape_a) + 1j * rng.standard_normal(shape_a)
+            b = rng.standard_normal(shape_b) + 1j * rng.standard_normal(shape_b)
+            dev_a, dev_b = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+            dev_c = torch.empty(m, n, dtype=torch.complex128, device="cuda")
+            _lib.call("qsv_tensor_gemm", 0, stream, op_a, op_b, m, n, k, C.c_void_p(dev_a.data_ptr()),
+                      C.c_void_p(dev_b.data_ptr()), C.c_void_p(dev_c.data_ptr()))
+            torch.cuda.synchronize()
+            want = form[op_a](a) @ form[op_b](b)
+            assert maxdiff(dev_c.cpu().numpy(), want) < 1e-13 * k, (op_a, op_b)
+
+
 @pytest.mark.parametrize("shape", [(700, 520), (300, 1100), (1024, 1024)])
 @pytest.mark.parametrize("options", [{"rel_err": 1e-2}, {"rel_err": 1e-3, "max_bond_dim": 40}, {"abs_err": 5e-3, "rel_err": 0.0},
                                      {"rel_err": 1e-5}])
