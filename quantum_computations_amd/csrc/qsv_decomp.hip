@@ -1042,7 +1042,9 @@ int qsvg_svd_split(int device, hipStream_t stream, amp_t *theta, uint64_t rows, 
     // zgesdd's answer is tried as it is only when the tolerance cannot tell the difference; under a tight one its factors
     // still seed the Jacobi sweeps over the whole matrix (jacobi_full_split), which then need a handful of sweeps
     const bool loose = !hopeless && (rel_err >= 1e-6 || abs_err > 0.0);
-    const bool jacobi_fits = jacobi_enabled && k >= 2 && k <= static_cast<uint64_t>(JACOBI_MAX_COLUMNS);
+    // (sweeps move the whole working matrix once per tournament step: beyond 2^26 amplitudes the library is no slower)
+    const bool jacobi_fits = jacobi_enabled && k >= 2 && k <= static_cast<uint64_t>(JACOBI_MAX_COLUMNS) &&
+                             rows * cols <= (1ull << 26);
     bool have_seed = false;
     if (a.zgesdd && gram_route_enabled && (loose || jacobi_fits)) {
         amp_t *backup = nullptr;
