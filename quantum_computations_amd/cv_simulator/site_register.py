@@ -71,6 +71,8 @@ class SiteRegister:
     def _upload(self, array, dtype=np.complex128):
         torch = _torch()
         host = np.ascontiguousarray(array, dtype=dtype)
+        if not host.flags.writeable:
+            host = host.copy()          # torch.from_numpy insists on a writable buffer (cached read-only operators)
         return torch.from_numpy(host).to(self._dev)
 
     def _empty(self, *shape):
@@ -104,7 +106,7 @@ class SiteRegister:
             return hit[1]
         dev = self._upload(host, dtype)
         self._resident[key] = (host, dev)
-        while len(self._resident) > 8:
+        while len(self._resident) > 16:
             self._resident.popitem(last=False)
         return dev
 
@@ -381,11 +383,11 @@ class SiteRegister:
         a, _, b = (int(v) for v in t1.shape)
         c = int(t2.shape[2])
         # [(a, i), k, b, dd] = t1[(a, i), b] * first[k, dd]  ->  rows (a, i), columns (k, b, dd)
-        joined = self._outer(t1, self._upload(first), a * d, d, b, chi, swap_last=False)
+        joined = self._outer(t1, self._keep(first), a * d, d, b, chi, swap_last=False)       # read only: a cached copy will do
         m1, m2, r1 = self._split(joined, a * d, d * b * chi, **truncation)
         new_t1, new_first = m1.reshape(a, d, r1), m2.reshape(r1, d, b * chi)
         # [b, dd, l, (j, c)] = second[dd, l] * t2[b, (j, c)]  ->  rows (b, dd, l), columns (j, c)
-        joined = self._outer(t2, self._upload(second), b, chi, d * c, d, swap_last=True)
+        joined = self._outer(t2, self._keep(second), b, chi, d * c, d, swap_last=True)
         m1, m2, r2 = self._split(joined, b * chi * d, d * c, **truncation)
         new_second, new_t2 = m1.reshape(b * chi, d, r2), m2.reshape(r2, d, c)
         self.sites[mode - 1:mode + 1] = [new_t1, new_first, new_second, new_t2]

@@ -22,6 +22,9 @@ PI = np.pi
 SQPI = np.sqrt(np.pi)
 
 
+_HALVES: dict = {}      # (pair, grid, epsilon) -> (first, second), see GKPBellState.halves
+
+
 class GKPBellState(Enum):
     PLUS = 1
     T = 2
@@ -45,10 +48,24 @@ class GKPBellState(Enum):
             raise ValueError("qs is not an arithmetic progression.")
         if gkp_epsilon is not None and gkp_epsilon <= 0:
             raise ValueError("epsilon must be a positive real number")
+        # every teleportation gadget inserts the same few pairs on the same grid (95 gadgets in the paper's Grover run):
+        # the two theta-function combs are evaluated once per (pair, grid, epsilon) and handed out read-only, which also
+        # lets the register keep ONE device copy of them (SiteRegister._keep goes by array identity)
+        key = (self.name, qs.shape[0], qs.dtype.str, qs.tobytes() if qs.shape[0] <= 4096 else None, gkp_epsilon)
+        hit = _HALVES.get(key) if key[3] is not None else None
+        if hit is not None:
+            return hit
         first = np.empty((len(qs), 2), dtype=complex)
         first[:, 0] = 2 ** (-1 / 4) * State.GKP_ZERO.eval(qs, gkp_epsilon)
         first[:, 1] = 2 ** (-1 / 4) * self._second_weight * State.GKP_ONE.eval(qs, gkp_epsilon)
-        return first, np.ascontiguousarray(first.T)
+        second = np.ascontiguousarray(first.T)
+        if key[3] is not None:
+            first.setflags(write=False)
+            second.setflags(write=False)
+            if len(_HALVES) >= 32:
+                _HALVES.clear()
+            _HALVES[key] = (first, second)
+        return first, second
 
     def eval(self, qs: np.ndarray, gkp_epsilon: float = None, *, device: int = 0) -> MPS:
         """The pair as a two-mode register (sites ``(1, d, 2)`` and ``(2, d, 1)``)."""
