@@ -1859,12 +1859,18 @@ int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream
     const uint64_t full = rows < cols ? rows : cols;
     if (full < 4 * static_cast<uint64_t>(LMAX)) return QSV_UNDECIDED;    // small matrices: the library SVD is cheap
     // the probe matrices and the norm partials live outside the pool (which rsvd_split_fused carves for itself) and are
-    // kept per device and width: the probes depend only on the size, so they are generated and uploaded once
+    // kept per device, width and matrix size: the probes depend only on those, so they are generated and uploaded once.
+    // (Several sizes per width: the thetas of one MPS alternate between a few shapes -- 1000, 2000, 4000 on the short side in
+    // the GKP runs -- and with ONE entry per width every change of shape cost a Box-Muller pass over 10^5 deviates on the
+    // host, a synchronising hipFree / hipMalloc and an upload.)
     struct Probes {
         amp_t *omega = nullptr;
         uint64_t count = 0;
+        uint64_t last_use = 0;
     };
-    static Probes cache[16][3];
+    constexpr int PROBE_SIZES = 8;
+    static Probes cache_sizes[16][3][PROBE_SIZES];
+    static uint64_t use_clock = 0;
     static double *norm_partials[16] = {nullptr};
     if (device < 0 || device >= 16) return QSV_UNDECIDED;  // no probe cache for this ordinal: take the exact route
     if (!norm_partials[device] &&
@@ -1890,8 +1896,22 @@ int try_verified_low_rank(RocblasApi &a, rocblas_handle h, int device, hipStream
     for (int w = 0; w < 3; ++w) {
         const int l = widths[w], keep = l - 10;
         if (full < 4 * static_cast<uint64_t>(l)) break;
-        Probes &probes = cache[device][w];
-        if (probes.count != full * l) {
+        Probes *slot = nullptr;
+        for (Probes &cand : cache_sizes[device][w])
+            if (cand.omega && cand.count == full * l) slot = &cand;
+        if (!slot) {               // a free entry, or the one that was used longest ago
+            slot = &cache_sizes[device][w][0];
+            for (Probes &cand : cache_sizes[device][w])
+                if (!cand.omega) {
+                    slot = &cand;
+                    break;
+                } else if (cand.last_use < slot->last_use) {
+                    slot = &cand;
+                }
+        }
+        Probes &probes = *slot;
+        probes.last_use = ++use_clock;
+        if (probes.count != full * l || !probes.omega) {
             if (probes.omega) {
                 (void)hipDeviceSynchronize();
                 (void)hipFree(probes.omega);
