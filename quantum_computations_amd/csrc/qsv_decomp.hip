@@ -1762,10 +1762,41 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
         const double f2 = verify->frobenius_squared;
         double rho2 = f2 - captured;
         double resolution = 4e-16 * static_cast<double>(L) * f2;
+        static const bool trace = std::getenv("QSV_TRACE_SPLIT") != nullptr;
+        uint64_t r_decided = 0;
+        // the acceptance test for a given bound on the missed mass: true = the rank is settled (in r_decided)
+        auto settled_with = [&](double rho2_bound) {
+            const double rho = sqrt(rho2_bound), margin = sqrt(static_cast<double>(verify->full_rank)) * rho;
+            const double allowed = allowed_error(sv, abs_err, rel_err);
+            if (trace)
+                fprintf(stderr, "[qsv split] %llu x %llu: probes %d, ||A||_F %.3e, rho %.3e, allowed %.3e, margin %.3e, s0 %.3e\n",
+                        static_cast<unsigned long long>(rows), static_cast<unsigned long long>(cols), l, sqrt(f2), rho, allowed,
+                        margin, sv[0]);
+            if (!(allowed > margin)) return false;
+            // true tail sums are the computed ones plus something in [0, margin]; the true allowance is the computed one
+            // plus at most rel_err * margin: the rank is settled if no computed tail sum falls between these two thresholds
+            const uint64_t r_lo = kept_rank_for(sv, verify->max_bond_dim, allowed + rel_err * margin);
+            const uint64_t r_hi = kept_rank_for(sv, verify->max_bond_dim, allowed - margin);
+            if (trace)
+                fprintf(stderr, "[qsv split]   r in [%llu, %llu], s[r-1] %.3e\n", static_cast<unsigned long long>(r_lo),
+                        static_cast<unsigned long long>(r_hi), r_lo > 0 ? sv[r_lo - 1] : 0.0);
+            // the kept triplets must sit well inside the captured block and far above what was missed (their subspace
+            // error after q power iterations is of order (rho / sigma_r)^(2q+1))
+            if (r_lo != r_hi || r_lo > static_cast<uint64_t>(k_keep) || (r_lo > 0 && !(sv[r_lo - 1] > 1e2 * rho))) return false;
+            r_decided = r_lo;
+            return true;
+        };
+        bool settled = false;
         if (rho2 < 1e-6 * f2) {
-            // The difference of the two norms is blind below ~1e-8 ||A||; a tight tolerance (the reference's default
-            // rel_err = 1e-12) needs better.  Evaluate the residual itself: (I - Q Q^H) A = A - (Q Rb^H) Qb^H entry by
-            // entry (A^H Q = Qb Rb was formed above), one l-term dot product per entry, rounding level ~l eps ||A||.
+            // The difference of the two norms is blind below ~1e-8 ||A||.  Under a loose tolerance that is still far more
+            // than the test needs: try it with the blind spot itself as the bound -- a wider margin can only leave the
+            // rank undecided, never change it (both thresholds move outwards) -- and only if that fails ...
+            settled = settled_with(rho2 > resolution ? rho2 : resolution);
+        }
+        if (!settled && rho2 < 1e-6 * f2) {
+            // ... (a tight tolerance: the reference's default rel_err = 1e-12) evaluate the residual itself:
+            // (I - Q Q^H) A = A - (Q Rb^H) Qb^H entry by entry (A^H Q = Qb Rb was formed above), one l-term dot product
+            // per entry, rounding level ~l eps ||A||.
             amp_t *Tp = nullptr;
             double *res_partials = nullptr;
             if (buf.alloc(&Tp, sizeof(amp_t) * n * L) && buf.alloc(&res_partials, sizeof(double) * 1024)) {
@@ -1784,26 +1815,9 @@ int rsvd_split_fused(RocblasApi &a, rocblas_handle h, int device, hipStream_t st
                 resolution = 1e-30 * static_cast<double>(L) * f2;
             }
         }
-        if (rho2 < resolution) rho2 = resolution;
-        const double rho = sqrt(rho2), margin = sqrt(static_cast<double>(verify->full_rank)) * rho;
-        const double allowed = allowed_error(sv, abs_err, rel_err);
-        static const bool trace = std::getenv("QSV_TRACE_SPLIT") != nullptr;
-        if (trace)
-            fprintf(stderr, "[qsv split] %llu x %llu: probes %d, ||A||_F %.3e, rho %.3e, allowed %.3e, margin %.3e, s0 %.3e\n",
-                    static_cast<unsigned long long>(rows), static_cast<unsigned long long>(cols), l, sqrt(f2), rho, allowed,
-                    margin, sv[0]);
-        if (!(allowed > margin)) return QSV_UNDECIDED;
-        // true tail sums are the computed ones plus something in [0, margin]; the true allowance is the computed one plus
-        // at most rel_err * margin: the rank is settled if no computed tail sum falls between these two thresholds
-        const uint64_t r_lo = kept_rank_for(sv, verify->max_bond_dim, allowed + rel_err * margin);
-        const uint64_t r_hi = kept_rank_for(sv, verify->max_bond_dim, allowed - margin);
-        if (trace)
-            fprintf(stderr, "[qsv split]   r in [%llu, %llu], s[r-1] %.3e\n", static_cast<unsigned long long>(r_lo),
-                    static_cast<unsigned long long>(r_hi), r_lo > 0 ? sv[r_lo - 1] : 0.0);
-        // the kept triplets must sit well inside the captured block and far above what was missed (their subspace error
-        // after q power iterations is of order (rho / sigma_r)^(2q+1))
-        if (r_lo != r_hi || r_lo > static_cast<uint64_t>(k_keep) || (r_lo > 0 && !(sv[r_lo - 1] > 1e2 * rho)))
-            return QSV_UNDECIDED;
+        if (!settled) settled = settled_with(rho2 > resolution ? rho2 : resolution);
+        if (!settled) return QSV_UNDECIDED;
+        const uint64_t r_lo = r_decided;
         r = r_lo;
         if (verify->values) {
             verify->values->assign(verify->full_rank, 0.0);
