@@ -104,6 +104,13 @@ def test_bell_pair_halves(ref):
         first, second = GKPBellState[name].halves(qs, eps)
         assert np.max(np.abs(first @ second - g[f"bell_{name}"])) < 1e-12
     assert repr(GKPBellState.T) == "GKP_BELL_T"
+    # evaluated once per (pair, grid, epsilon): the same read-only arrays come back (one device copy per register),
+    # another grid or epsilon gets its own
+    again = GKPBellState.PLUS.halves(qs.copy(), eps)
+    assert again[0] is GKPBellState.PLUS.halves(qs, eps)[0] and not again[0].flags.writeable
+    other = GKPBellState.PLUS.halves(qs * 1.01, eps)
+    assert other[0] is not again[0] and np.max(np.abs(other[0] - again[0])) > 1e-6
+    assert GKPBellState.PLUS.halves(qs, eps * 1.1)[0] is not again[0]
     with pytest.raises(TypeError):
         InsertBell(0, "PLUS")
     with pytest.raises(ValueError):
