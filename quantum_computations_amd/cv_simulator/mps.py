@@ -38,7 +38,7 @@ def tensor_svd(tensor, left_indices, right_indices, *, max_bond_dim: int = np.in
     matrix = np.moveaxis(np.asarray(tensor), left_indices + right_indices, range(len(shape))).reshape(rows, cols)
     worker = SiteRegister([], 1, device)
     m1, m2, r = worker._split(worker._upload(matrix), rows, cols, max_bond_dim=max_bond_dim, abs_err=abs_err,
-                              rel_err=rel_err)
+                              rel_err=rel_err, rng_seed=rng_seed)
     return (m1.cpu().numpy().reshape([shape[i] for i in left_indices] + [r]),
             m2.cpu().numpy().reshape([r] + [shape[i] for i in right_indices]))
 

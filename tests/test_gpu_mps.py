@@ -100,6 +100,57 @@ def test_randomized_split_on_a_low_rank_matrix():
         assert maxdiff(np.tensordot(m1, m2, axes=1).reshape(matrix.shape), matrix) < 1e-9 * np.abs(matrix).max()
 
 
+def test_randomized_split_asks_for_its_test_matrix_only_when_it_reads_it():
+    """``qsv_tensor_rsvd_split`` without a test matrix (``dev_omega = NULL``): a split the verified low-rank route decides
+    (loose tolerance, more than 64 probes asked for) is answered at once; one it cannot decide -- or a panel of at most 64
+    probes, which goes straight to the caller's matrix -- reports ``QSV_RANK_NEEDS_OMEGA`` and computes nothing; the second
+    call with the matrix gives what a call with the matrix from the start gives.  A ``Generator`` handed down as
+    ``rng_seed`` is advanced by the draw in either case (the reference's ``default_rng(generator)`` is the generator)."""
+    import ctypes as C
+
+    import torch
+
+    from quantum_computations_amd import _lib
+    rng = np.random.default_rng(5)
+    rows, cols, k, probes = 1200, 900, 70, 80
+    u, _ = np.linalg.qr(rng.standard_normal((rows, cols)) + 1j * rng.standard_normal((rows, cols)))
+    v, _ = np.linalg.qr(rng.standard_normal((cols, cols)) + 1j * rng.standard_normal((cols, cols)))
+    low = (u * np.exp(-np.arange(cols) / 2.0)) @ v.conj().T                   # numerical rank ~ 30 at rel_err = 1e-3
+    flat = (u * np.linspace(1.0, 0.5, cols)) @ v.conj().T                     # nothing to truncate: no verified answer
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    omega = np.random.default_rng(9).normal(0, 1, size=(cols, probes))
+    dev_omega = torch.from_numpy(np.ascontiguousarray(np.asfortranarray(omega).T, dtype=np.complex128)).cuda()
+
+    def split(matrix, with_omega, rel_err, n_probes=probes, keep=k):
+        dev = torch.from_numpy(matrix).cuda()
+        m1 = torch.empty(rows * keep, dtype=torch.complex128, device="cuda")
+        m2 = torch.empty(keep * cols, dtype=torch.complex128, device="cuda")
+        rank = C.c_uint64(0)
+        s = np.empty(keep)
+        _lib.call("qsv_tensor_rsvd_split", 0, stream, C.c_void_p(dev.data_ptr()), rows, cols, keep, n_probes, 4,
+                  C.c_void_p(dev_omega.data_ptr()) if with_omega else None, 0.0, rel_err, C.c_void_p(m1.data_ptr()),
+                  C.c_void_p(m2.data_ptr()), keep, C.byref(rank), s.ctypes.data_as(C.c_void_p))
+        torch.cuda.synchronize()
+        r = int(rank.value)
+        if r == _lib.RANK_NEEDS_OMEGA:
+            return r, None
+        return r, (m1[: rows * r].view(rows, r) @ m2[: r * cols].view(r, cols)).cpu().numpy()
+
+    r, product = split(low, False, 1e-3)
+    assert r != _lib.RANK_NEEDS_OMEGA and 10 < r < k and maxdiff(product, low) < 2e-3 * np.abs(low).max() * r
+    r, product = split(flat, False, 1e-3)
+    assert r == _lib.RANK_NEEDS_OMEGA and product is None
+    r_again, with_matrix = split(flat, True, 1e-3)
+    r_direct, direct = split(flat, True, 1e-3)
+    assert r_again == r_direct == k and np.array_equal(with_matrix, direct)
+    # the host side: tensor_svd with a Generator as rng_seed leaves it where the reference's draw would
+    t = low.reshape(rows, 1, 1, cols)
+    gen, twin = np.random.default_rng(21), np.random.default_rng(21)
+    tensor_svd(t, [0, 1], [2, 3], max_bond_dim=k, rel_err=1e-3, rng_seed=gen)
+    twin.normal(0, 1, size=(cols, k + 10))
+    assert gen.random() == twin.random()
+
+
 def test_library_qr_path_of_the_randomized_split_still_works():
     """``QSV_RSVD=rocsolver`` selects rocSOLVER's Householder QR / gesvd instead of the fused panel kernels; the choice is
     read once per process, so the check runs in a child process."""
