@@ -63,11 +63,19 @@ def syndrome_matrix(syndromes: list[tuple[int, int]]) -> np.ndarray:
     return npq.tensor(*factors)
 
 
+_READOUT_OPERATORS: dict = {}      # grid -> [I, X, Y, Z] read-out operators, see pauli_readout_operators
+
+
 def pauli_readout_operators(qs: np.ndarray) -> list[np.ndarray]:
     """Grid operators ``[I, X, Y, Z]`` whose expectation values are the logical Bloch components: truncated Fourier
     series of the sqrt(pi)-periodic sign functions -- odd multiples ``m`` of sqrt(pi), coefficients ``±2/(m pi)``,
     displacements realised by sinc interpolation and the momentum-like ones by cosines (utils.py:48-71; appendix D
     of Shaw et al., arXiv:2403.02396).  The quirks are kept: the spacing here is ``(q_max - q_min) / len(qs)``."""
+    # the operators depend on the grid alone (0.2 s of sinc evaluations at d = 1000): one set per grid is kept, read-only,
+    # which also lets a register keep ONE device copy of each (SiteRegister._keep goes by array identity)
+    key = (qs.shape[0], qs.dtype.str, qs.tobytes()) if isinstance(qs, np.ndarray) and qs.ndim == 1 and qs.shape[0] <= 4096 else None
+    if key is not None and key in _READOUT_OPERATORS:
+        return _READOUT_OPERATORS[key]
     d = len(qs)
     dq = (qs[-1] - qs[0]) / d
     offsets = qs[:, None] - qs[None, :]
@@ -76,7 +84,14 @@ def pauli_readout_operators(qs: np.ndarray) -> list[np.ndarray]:
         weight = (-1) ** (n % 2) * 2 / (m * PI)
         shift += weight * (np.sinc((offsets - m * SQPI) / dq) + np.sinc((offsets + m * SQPI) / dq))
         phase += weight * np.diag(2 * np.cos(SQPI * m * qs))
-    return [np.identity(d), shift, 1j * shift @ phase, phase]
+    operators = [np.identity(d), shift, 1j * shift @ phase, phase]
+    if key is not None:
+        for op in operators:
+            op.setflags(write=False)
+        if len(_READOUT_OPERATORS) >= 2:
+            _READOUT_OPERATORS.clear()
+        _READOUT_OPERATORS[key] = operators
+    return operators
 
 
 def full_logical_density_mps(mps: MPS, normalised: bool = False) -> np.ndarray:
