@@ -143,6 +143,28 @@ __global__ __launch_bounds__(256) void k_panel_gram(const amp_t *__restrict__ Y,
     }
 }
 
+// partials[0][e] = partials[0][e] + partials[1][e] + ... in block order, one entry per thread with every load in flight:
+// inside k_panel_factor (one workgroup, 128 registers per thread) that sum was a chain of load batches from another XCD's
+// L2 -- 26 of the kernel's 80 us.
+__global__ __launch_bounds__(256) void k_gram_reduce(amp_t *__restrict__ partials, int nblocks, int entries,
+                                                    const int *__restrict__ skip) {
+    if (skip && *skip) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= entries) return;
+    amp_t v[GRAM_BLOCKS];
+#pragma unroll
+    for (int b = 0; b < GRAM_BLOCKS; ++b)
+        if (b < nblocks) v[b] = partials[static_cast<size_t>(b) * entries + e];
+    amp_t s = {0.0, 0.0};
+#pragma unroll
+    for (int b = 0; b < GRAM_BLOCKS; ++b)
+        if (b < nblocks) {
+            s.x += v[b].x;
+            s.y += v[b].y;
+        }
+    partials[e] = s;
+}
+
 // (1024 threads: the sum of the 64 partial Gram matrices is a chain of load batches per thread -- 16 entries x 2 batches
 // with 256 threads, 130 us per launch on average and 29 % of the GPU time of the GKP Grover experiment; four times the
 // threads quarter the chain, and the trailing updates of the factorisation shrink with it)
@@ -223,31 +245,28 @@ __global__ __launch_bounds__(FACTOR_THREADS) void k_panel_factor(const amp_t *__
         const int nb = l - jb < NB ? l - jb : NB;
         __syncthreads();
         if (t < 64) {
+            // lane (i, k) = (t / 8, t % 8) keeps entry (i, k) of the block in a register; the pivot and the two factors of
+            // every update come from the lanes of row p by wave shuffles -- the same operations on the same values as a
+            // walk through LDS (which cost three LDS round trips per pivot: 3.2 us per block, a third of this kernel)
+            const int i = t / NB, k = t % NB;
+            const bool inside = i < nb && k < nb;
+            amp_t g = inside ? G[(jb + i) * l + jb + k] : amp_t{0.0, 0.0};
             for (int p = 0; p < nb; ++p) {
-                const int j = jb + p;
-                const double pivot = G[j * l + j].x + shift;
+                const double pivot = __shfl(g.x, p * NB + p, 64) + shift;
                 const bool gone = !(pivot > pivot_floor);
                 const double rjj = gone ? 1.0 : sqrt(pivot);
-                __builtin_amdgcn_wave_barrier();
-                if (t == 0) {
-                    G[j * l + j] = amp_t{rjj, 0.0};
-                    absent[j] = gone;
+                if (i == p && k == p) g = amp_t{rjj, 0.0};
+                else if (i == p && k > p && inside) g = gone ? amp_t{0.0, 0.0} : amp_t{g.x / rjj, g.y / rjj};   // the rest of row p
+                if (t == 0) absent[jb + p] = gone;
+                const amp_t ri = {__shfl(g.x, p * NB + i, 64), __shfl(g.y, p * NB + i, 64)};      // R[p][i]
+                const amp_t rk = {__shfl(g.x, p * NB + k, 64), __shfl(g.y, p * NB + k, 64)};      // R[p][k]
+                if (i > p && k >= i && inside) {     // the block's remaining entries (i, k), p < i <= k < nb
+                    const amp_t pr = conj_mul(ri, rk);
+                    g.x -= pr.x;
+                    g.y -= pr.y;
                 }
-                if (t > p && t < nb) {      // the rest of row j inside the diagonal block
-                    const amp_t v = G[j * l + jb + t];
-                    G[j * l + jb + t] = gone ? amp_t{0.0, 0.0} : amp_t{v.x / rjj, v.y / rjj};
-                }
-                __builtin_amdgcn_wave_barrier();
-                {                           // update of the block's remaining entries (i, k), p < i <= k < nb
-                    const int i = t / NB, k = t % NB;
-                    if (i > p && k >= i && k < nb && i < nb) {
-                        const amp_t pr = conj_mul(G[j * l + jb + i], G[j * l + jb + k]);
-                        G[(jb + i) * l + jb + k].x -= pr.x;
-                        G[(jb + i) * l + jb + k].y -= pr.y;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
             }
+            if (inside && k >= i) G[(jb + i) * l + jb + k] = g;
         }
         __syncthreads();
         // block row: R[jb + p][k] for k beyond the block, by forward substitution with the block's R^H
@@ -1427,7 +1446,9 @@ int panel_orthonormalise(hipStream_t stream, amp_t *Y, uint64_t n, int l, amp_t 
         int *next = flags && round < 2 ? flags + round + 1 : nullptr;
         if (tiles <= 256) hipLaunchKernelGGL(k_panel_gram<4>, dim3(gram_blocks, 4), dim3(256), lds, stream, Y, n, l, partials, skip);
         else hipLaunchKernelGGL(k_panel_gram<1>, dim3(gram_blocks), dim3(256), lds, stream, Y, n, l, partials, skip);
-        hipLaunchKernelGGL(k_panel_factor, dim3(1), dim3(FACTOR_THREADS), 0, stream, partials, gram_blocks, l, n, round == 0,
+        if (gram_blocks > 1)
+            hipLaunchKernelGGL(k_gram_reduce, dim3((l * l + 255) / 256), dim3(256), 0, stream, partials, gram_blocks, l * l, skip);
+        hipLaunchKernelGGL(k_panel_factor, dim3(1), dim3(FACTOR_THREADS), 0, stream, partials, 1, l, n, round == 0,
                            round == 0 ? nullptr : r_total, r_total, r_factor, skip, next);
         hipLaunchKernelGGL(k_panel_solve, dim3(apply_blocks), dim3(256), lds + sizeof(amp_t) * l * l, stream, Y, n, l,
                            r_factor, skip);
