@@ -89,6 +89,42 @@ __global__ __launch_bounds__(QSV_BLOCK) void k_axis_simple(const amp_t *__restri
     }
 }
 
+// Thin fibres (R <= 8: the sites of a matrix-product state with bonds of 1-2, d = 1000 -- every single-mode gate of the
+// GKP runs): a WAVE per output row (l, i), lanes striding over j, so the operator row is read as whole 1 KiB segments
+// (k_axis_simple reads it one 16-byte entry per thread, rows apart: 224 us for a 1000 x 1000 operator on a (1, 1000, 2)
+// site, 16 MB that HBM delivers in a few microseconds).  Per-lane partial sums, then a shuffle tree.
+__global__ __launch_bounds__(QSV_BLOCK) void k_axis_rows(const amp_t *__restrict__ in, amp_t *__restrict__ out, uint64_t L,
+                                                        int d_in, int d_out, int R, const double *__restrict__ M) {
+    constexpr int RMAX = 8;
+    const uint64_t row = static_cast<uint64_t>(blockIdx.x) * (QSV_BLOCK / 64) + (threadIdx.x >> 6);
+    if (row >= L * static_cast<uint64_t>(d_out)) return;      // whole waves leave together
+    const int lane = threadIdx.x & 63;
+    const uint64_t l = row / d_out, i = row % d_out;
+    amp_t acc[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) acc[r] = amp_t{0.0, 0.0};
+    const amp_t *mrow = reinterpret_cast<const amp_t *>(M) + i * static_cast<uint64_t>(d_in);
+    for (int j = lane; j < d_in; j += 64) {
+        const amp_t mv = mrow[j];
+        const cplx m = {mv.x, mv.y};
+        const amp_t *x = in + (l * d_in + j) * static_cast<uint64_t>(R);
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r)
+            if (r < R) acc[r] = cfma(m, x[r], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+        if (r < R) {
+            double re = acc[r].x, im = acc[r].y;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                re += __shfl_xor(re, o, 64);
+                im += __shfl_xor(im, o, 64);
+            }
+            if (lane == 0) out[row * R + r] = amp_t{re, im};
+        }
+}
+
 // in[l, j, r] *= diag[j]
 __global__ __launch_bounds__(QSV_BLOCK) void k_axis_diag(amp_t *__restrict__ a, uint64_t total, int d, uint64_t R,
                                                         const double *__restrict__ diag) {
@@ -431,6 +467,14 @@ int grid_of(uint64_t items, int per_block, int cap) {
     return static_cast<int>(b);
 }
 
+static bool axis_rows_enabled() {       // QSV_AXIS_ROWS=0: thin fibres through k_axis_simple, for comparisons
+    static const bool on = [] {
+        const char *e = getenv("QSV_AXIS_ROWS");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 int launch_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out, uint64_t L, uint64_t d_in,
                 uint64_t d_out, uint64_t R, const double *dev_m) {
     // grids of >= 64 points with enough work to fill the chip are plain GEMMs: rocBLAS (f64 MFMA), qsv_gemm.hip
@@ -447,6 +491,10 @@ int launch_axis(int device, hipStream_t stream, const amp_t *in, amp_t *out, uin
                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         hipLaunchKernelGGL(k_axis_tile, dim3(grid), dim3(QSV_BLOCK), lds, stream, in, out, L, static_cast<int>(d_in),
                            static_cast<int>(d_out), R, r_tiles, dev_m);
+    } else if (R <= 8 && d_in >= 128 && L * d_out <= (1ull << 31) && axis_rows_enabled()) {
+        const uint64_t rows = L * d_out, per_block = QSV_BLOCK / 64;
+        hipLaunchKernelGGL(k_axis_rows, dim3(static_cast<unsigned>((rows + per_block - 1) / per_block)), dim3(QSV_BLOCK), 0,
+                           stream, in, out, L, static_cast<int>(d_in), static_cast<int>(d_out), static_cast<int>(R), dev_m);
     } else {
         const int grid = grid_of(L * d_out * R, QSV_BLOCK, 1 << 16);
         hipLaunchKernelGGL(k_axis_simple, dim3(grid), dim3(QSV_BLOCK), 0, stream, in, out, L,

@@ -173,7 +173,10 @@ def test_squeezing_and_phase_on_the_grid():
 
 @pytest.mark.parametrize("L,d_in,d_out,R", [(3, 40, 40, 100), (1, 64, 48, 7), (5, 1000, 1000, 2), (2, 130, 130, 70),
                                           # grids large enough for the rocBLAS route (qsv_gemm.hip): R > 1, R == 1, rectangular
-                                          (20, 256, 256, 20), (4096, 128, 128, 1), (6, 200, 72, 300)])
+                                          (20, 256, 256, 20), (4096, 128, 128, 1), (6, 200, 72, 300),
+                                          # thin fibres (bonds of 1-2 on d = 1000 grids): a wave per output row, k_axis_rows
+                                          (1, 1000, 1000, 1), (1, 1000, 1000, 2), (2, 1000, 1000, 1), (3, 257, 129, 5),
+                                          (2, 128, 200, 8), (1, 130, 1, 3)])
 def test_tensor_apply_axis_on_mps_sites(L, d_in, d_out, R):
     """out[l, :, r] = M @ in[l, :, r] on a raw (chi_l, d, chi_r) site, as utils.py:15-16 does with tensordot."""
     import torch
