@@ -72,10 +72,15 @@ enum {
     QSV_OPT_COMPLEX_PRODUCT = 10, /* complex 32 x 32 / 64 x 64 blocks (qsv_apply_kq, k = 5, 6): 0 (default) = three real
                                 multiplications per matrix entry (Ar xr, Ai xi, (Ar + Ai)(xr + xi)), 4 = four.  Equal
                                 to rounding (normwise); for measurements */
-    QSV_OPT_SEQUENCE_WORK = 11  /* qsv_apply_sequence: the largest gate sequence applied as a sequence, in multiply-adds
+    QSV_OPT_SEQUENCE_WORK = 11, /* qsv_apply_sequence: the largest gate sequence applied as a sequence, in multiply-adds
                                 per 32 amplitudes (256 per one-qubit gate, 512 per two-qubit gate; the dense block costs
                                 4096).  Longer sequences report handled = 0.  -1 (default) = $QSV_SEQUENCE_WORK or 0, 0 = never: the
                                 sequence form measured no faster than the dense block; kept for measurements */
+    QSV_OPT_TILE_SEQUENCE_GATES = 12 /* qsv_apply_sequence: blocks made of at most this many 1- and 2-qubit gates are
+                                applied as that gate list on LDS-resident tiles (k_seq_tile) instead of their dense
+                                product.  -1 (default) = 6-qubit blocks of at most 12 gates ($QSV_TILE_SEQUENCE_GATES);
+                                an explicit value also admits 5-qubit blocks (slower than their dense product: for
+                                measurements); 0 = never */
 };
 
 typedef struct qsv_state qsv_state;

@@ -11,6 +11,7 @@ LIB_PATH = Path(os.environ.get("QSV_LIBRARY", PKG_DIR / "libqsv.so"))
 QSV_OK, QSV_EINVAL, QSV_ENOMEM, QSV_EHIP, QSV_ESTATE = 0, -1, -2, -3, -4
 OPT_SPECIALIZE, OPT_UNROLL, OPT_GRID_CAP, OPT_NONTEMPORAL, OPT_ITEM_STRIDE_BIT, OPT_TILE_REGIONS = 1, 2, 3, 4, 5, 6
 OPT_KQ_VARIANT, OPT_PLANE_KERNEL, OPT_READOUT_VARIANT, OPT_COMPLEX_PRODUCT, OPT_SEQUENCE_WORK = 7, 8, 9, 10, 11
+OPT_TILE_SEQUENCE_GATES = 12
 
 RANK_NEEDS_OMEGA = (1 << 64) - 1     # qsv_tensor_rsvd_split without a test matrix: call again with one
 

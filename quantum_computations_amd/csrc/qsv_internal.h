@@ -85,6 +85,8 @@ struct qsv_state {
     int remap = -1;                   // tile order: -1 = per-kernel default, 0 = plain, R = regions
     int kq_variant = 0;               // k = 3..5 gates: 0 = per-case choice, 1 = wave shuffles (k_dense_big<K, KL>),
                                       // 2 = no transpose (per-thread strided access), 3 = line-granular (k_dense_lds)
+    int last_passes = 0;              // k_seq_tile: LDS passes of the last gate list (diagnostics)
+    int tile_sequence_gates = -1;     // qsv_apply_sequence: longest gate list applied on LDS tiles (-1 = built-in, 0 = never)
     int sequence_work = -1;           // qsv_apply_sequence: multiply-add limit per 32 amplitudes (-1 = built-in, 0 = never)
     int complex_product = 0;          // complex 5- / 6-qubit blocks: 0 = three real multiplications per entry (3M),
                                       // 4 = the four-multiplication form (measurement variant)
@@ -125,6 +127,7 @@ int qsvk_diag(qsv_state *st, int k, const int *bits, int nctrl, const int *cbits
 int qsvk_phase(qsv_state *st, int nctrl, const int *cbits, double re, double im);
 int qsvk_generic(qsv_state *st, int k, const int *bits, const double *m_user);
 int qsvk_sequence5(qsv_state *st, const int *bits, int n_gates, const int *arity, const int *legs, const double *mats);
+int qsvk_sequence_tile(qsv_state *st, int k, const int *bits, int n_gates, const int *arity, const int *legs, const double *mats);
 constexpr int QSV_UNHANDLED_KQ = 1 << 20;  // internal: "not this kernel's case"
 int qsvk_measure_probs(qsv_state *st, int bit, const double eig0[4], const double eig1[4], double *p0, double *p1);
 int qsvk_collapse(qsv_state *st, int bit, const double eig[4], double scale);

@@ -16,6 +16,7 @@
 #include "qsv_internal.h"
 
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -533,11 +534,11 @@ static int seq_max_work() {
     return v;
 }
 
-template <int J>
-__device__ __forceinline__ void seq_apply1(amp_t (&x)[32], const double *__restrict__ m) {
+template <int J, int D = 32>
+__device__ __forceinline__ void seq_apply1(amp_t (&x)[D], const double *__restrict__ m) {
     const cplx m00{m[0], m[1]}, m01{m[2], m[3]}, m10{m[4], m[5]}, m11{m[6], m[7]};
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
+    for (int c = 0; c < D; ++c) {
         if (c & (1 << J)) continue;
         const amp_t a0 = x[c], a1 = x[c | (1 << J)];
         x[c] = cfma(m01, a1, cmul(m00, a0));
@@ -545,10 +546,10 @@ __device__ __forceinline__ void seq_apply1(amp_t (&x)[32], const double *__restr
     }
 }
 
-template <int HI, int LO>
-__device__ __forceinline__ void seq_apply2(amp_t (&x)[32], const double *__restrict__ m) {
+template <int HI, int LO, int D = 32>
+__device__ __forceinline__ void seq_apply2(amp_t (&x)[D], const double *__restrict__ m) {
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
+    for (int c = 0; c < D; ++c) {
         if (c & ((1 << HI) | (1 << LO))) continue;
         const amp_t in[4] = {x[c], x[c | (1 << LO)], x[c | (1 << HI)], x[c | (1 << HI) | (1 << LO)]};
 #pragma unroll
@@ -2084,6 +2085,98 @@ __global__ __launch_bounds__((1 << K) / ROWS * 64) void k_dense_tile(amp_t *__re
     }
 }
 
+// ---- a fused block as the SEQUENCE of its source gates on an LDS-resident tile (round 3) -------------------------------
+// Dense 5- and 6-qubit blocks are the gate shapes bound by arithmetic (4 x 32 / 3 x 64 real multiply-adds per amplitude at
+// a power-limited clock: 1.6 / 1.9 ms against the 1.31 ms of a pass over HBM), yet a fused block is the product of a
+// handful of 1- and 2-qubit gates worth 4-8 multiply-adds each.  Here a workgroup brings a 4096-amplitude tile into LDS
+// -- the block's K target bits plus the 12 - K lowest other bits: every row of the tile is 64 contiguous amplitudes (bits
+// 0-5 are always in the tile when K <= 6), so HBM sees whole 1 KiB runs in both directions, straight into LDS on the way
+// in -- and applies the source gates one after the other on that 12-qubit register (a barrier between gates), as the
+// single-launch executor does with whole registers (qsv_circuit.hip).  Two workgroups per CU: one computes while the
+// other loads or stores.
+// The gate list is cut into PASSES over at most four tile bits each (consecutive gates whose legs fit four bits together):
+// a thread takes the 16 amplitudes of one group of the pass's four bits into registers, applies the pass's gates there
+// (seq_apply*: compile-time register indices behind a wave-uniform switch) and puts them back -- one LDS round trip and one
+// barrier per pass instead of one per gate.
+struct TilePass {
+    int32_t first, count;      // gates [first, first + count) of the SeqGate list (codes relative to the pass's four bits)
+    int32_t q[4];              // the pass's tile bits, ascending
+    int32_t pad[2];
+};
+
+constexpr int TILE_SEQ_BITS = 12, TILE_SEQ_ROWS = 1 << (TILE_SEQ_BITS - 6), TILE_SEQ_THREADS = 256, TILE_SEQ_MAX_PASSES = 24;
+constexpr int TILE_SEQ_ROWS_PER_WAVE = TILE_SEQ_ROWS / (TILE_SEQ_THREADS / 64);
+
+struct TileSeqArgs {
+    BigArgs g;              // pos[] = ALL tile bits: the tile number is deposited around them
+    uint32_t lane_bit[6];   // address bit of lane bit j (the six lowest tile bits: 0..5 unless a 6-qubit block sits above them)
+};
+
+__device__ __forceinline__ void seq_run16(amp_t (&x)[16], const SeqGate *__restrict__ gates, int n_gates) {
+#pragma unroll 1
+    for (int g = 0; g < n_gates; ++g) {
+        const double *m = gates[g].m;
+        switch (gates[g].code) {     // wave-uniform (scalar loads): 0..3 one-qubit gates, 5 + p two-qubit gates as in SeqGate
+            case 0: seq_apply1<0, 16>(x, m); break;
+            case 1: seq_apply1<1, 16>(x, m); break;
+            case 2: seq_apply1<2, 16>(x, m); break;
+            case 3: seq_apply1<3, 16>(x, m); break;
+            case 5: seq_apply2<1, 0, 16>(x, m); break;
+            case 6: seq_apply2<2, 0, 16>(x, m); break;
+            case 7: seq_apply2<2, 1, 16>(x, m); break;
+            case 8: seq_apply2<3, 0, 16>(x, m); break;
+            case 9: seq_apply2<3, 1, 16>(x, m); break;
+            default: seq_apply2<3, 2, 16>(x, m); break;
+        }
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(TILE_SEQ_THREADS) void k_seq_tile(amp_t *__restrict__ a, const TileSeqArgs ta,
+                                                              const SeqGate *__restrict__ gates,
+                                                              const TilePass *__restrict__ passes, int n_passes,
+                                                              const uint64_t *__restrict__ off) {   // [rows] row offsets
+    const BigArgs &g = ta.g;
+    extern __shared__ __attribute__((aligned(16))) char seq_smem[];
+    amp_t *tile = reinterpret_cast<amp_t *>(seq_smem);        // [rows][64 lanes] = the tile register, index row * 64 + lane
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave q: rows q RPW .. q RPW + RPW - 1
+    constexpr int RPW = TILE_SEQ_ROWS_PER_WAVE;
+    const uint64_t tile_id = (g.regions > 1 && gridDim.x % g.regions == 0)
+                                 ? (blockIdx.x % g.regions) * (gridDim.x / g.regions) + blockIdx.x / g.regions
+                                 : blockIdx.x;
+    uint64_t base = deposit(g.w0 + tile_id, g);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) base |= static_cast<uint64_t>((lane >> j) & 1) << ta.lane_bit[j];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+        __builtin_amdgcn_global_load_lds(a + base + off[q * RPW + i], tile + (q * RPW + i) * 64, 16, 0, NT ? 2 : 0);
+#endif
+    __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < n_passes; ++p) {
+        const TilePass &ps = passes[p];
+        // the groups of the pass: their index bits with zeros inserted at the pass's four tile bits
+        for (uint32_t grp = threadIdx.x; grp < (1u << (TILE_SEQ_BITS - 4)); grp += TILE_SEQ_THREADS) {
+            uint32_t g0 = grp;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g0 = static_cast<uint32_t>(insert_zero(g0, ps.q[j]));
+            amp_t x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                x[c] = tile[g0 | ((c & 1) << ps.q[0]) | (((c >> 1) & 1) << ps.q[1]) | (((c >> 2) & 1) << ps.q[2]) | (((c >> 3) & 1) << ps.q[3])];
+            seq_run16(x, gates + ps.first, ps.count);
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                tile[g0 | ((c & 1) << ps.q[0]) | (((c >> 1) & 1) << ps.q[1]) | (((c >> 2) & 1) << ps.q[2]) | (((c >> 3) & 1) << ps.q[3])] = x[c];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) st<NT>(a + base + off[q * RPW + i], tile[(q * RPW + i) * 64 + lane]);
+}
+
 // Complex 5-qubit blocks: the LDS tile of k_dense_tile feeding the f64 MATRIX CORES (round 3).  The vector kernels spend
 // 4 x 32 FP64 FMAs per amplitude; rocprofv3's SQ counters put their vector pipe at 81 % busy over the whole launch, at a
 // clock that the FP64 load pulls down to ~1.65 GHz (a 1-qubit gate runs at 2.3): they are bound by arithmetic, and the
@@ -2749,6 +2842,134 @@ int qsvk_sequence5(qsv_state *st, const int *bits, int n_gates, const int *arity
             default: QSV_LAUNCH_SEQ(3); break;
         }
 #undef QSV_LAUNCH_SEQ
+        rc = check_launch();
+        if (rc) return rc;
+    }
+    return qsvk_stage_done(st, staged);
+}
+
+// A fused block of k = 1..6 qubits as the list of its source gates on LDS tiles (k_seq_tile).  Arguments as
+// qsvk_sequence5.  QSV_UNHANDLED_KQ: the register is too small for a tile, a gate acts on more than two qubits, or the
+// list needs more passes than the kernel's table holds.
+int qsvk_sequence_tile(qsv_state *st, int k, const int *bits, int n_gates, const int *arity, const int *legs,
+                       const double *mats) {
+    if (k < 1 || k > 6 || n_gates < 1 || n_gates > SEQ_MAX_GATES || st->n < TILE_SEQ_BITS) return QSV_UNHANDLED_KQ;
+    // the tile's bits: the targets and the lowest other bits, 12 in all, ascending
+    std::vector<int> tile_bits(bits, bits + k);
+    for (int b = 0; b < st->n && static_cast<int>(tile_bits.size()) < TILE_SEQ_BITS; ++b)
+        if (std::find(bits, bits + k, b) == bits + k) tile_bits.push_back(b);
+    std::sort(tile_bits.begin(), tile_bits.end());
+    auto position = [&](int bit) { return static_cast<int>(std::find(tile_bits.begin(), tile_bits.end(), bit) - tile_bits.begin()); };
+    // passes: consecutive gates whose legs fit four tile bits together
+    struct Draft {
+        std::vector<int> q;      // tile bits of the pass
+        std::vector<int> gate;   // indices into the gate list
+    };
+    std::vector<Draft> drafts;
+    std::vector<std::array<int, 2>> where(n_gates);
+    for (int gi = 0; gi < n_gates; ++gi) {
+        if (arity[gi] != 1 && arity[gi] != 2) return QSV_UNHANDLED_KQ;
+        for (int j = 0; j < 2; ++j) {
+            const int leg = legs[2 * gi + (j < arity[gi] ? j : 0)];
+            if (leg < 0 || leg >= k) return qsv_fail(QSV_EINVAL, "gate sequence: leg outside the block");
+            where[gi][j] = position(bits[leg]);
+        }
+        if (arity[gi] == 2 && where[gi][0] == where[gi][1]) return qsv_fail(QSV_EINVAL, "gate sequence: legs outside the block");
+        std::vector<int> merged = drafts.empty() ? std::vector<int>() : drafts.back().q;
+        for (int j = 0; j < arity[gi]; ++j)
+            if (std::find(merged.begin(), merged.end(), where[gi][j]) == merged.end()) merged.push_back(where[gi][j]);
+        if (drafts.empty() || merged.size() > 4) {
+            drafts.push_back(Draft{});
+            merged.assign(where[gi].begin(), where[gi].begin() + arity[gi]);
+        }
+        drafts.back().q = merged;
+        drafts.back().gate.push_back(gi);
+    }
+    if (drafts.size() > static_cast<size_t>(TILE_SEQ_MAX_PASSES)) return QSV_UNHANDLED_KQ;
+    std::vector<TilePass> passes(drafts.size());
+    std::vector<SeqGate> rec(n_gates);
+    std::vector<size_t> mat_at(n_gates);
+    {
+        size_t at = 0;
+        for (int gi = 0; gi < n_gates; ++gi) {
+            mat_at[gi] = at;
+            at += arity[gi] == 1 ? 8 : 32;
+        }
+    }
+    int next = 0;
+    for (size_t p = 0; p < drafts.size(); ++p) {
+        Draft &d = drafts[p];
+        for (int b = 0; d.q.size() < 4; ++b)          // fewer than four bits in use: any other tile bits complete the group
+            if (std::find(d.q.begin(), d.q.end(), b) == d.q.end()) d.q.push_back(b);
+        std::sort(d.q.begin(), d.q.end());
+        TilePass &ps = passes[p];
+        std::memset(&ps, 0, sizeof(ps));
+        ps.first = next;
+        ps.count = static_cast<int32_t>(d.gate.size());
+        for (int j = 0; j < 4; ++j) ps.q[j] = d.q[j];
+        for (int gi : d.gate) {
+            SeqGate &r = rec[next++];
+            std::memset(&r, 0, sizeof(r));
+            const double *m = mats + mat_at[gi];
+            auto local = [&](int tile_bit) { return static_cast<int>(std::find(d.q.begin(), d.q.end(), tile_bit) - d.q.begin()); };
+            if (arity[gi] == 1) {
+                r.code = local(where[gi][0]);
+                std::memcpy(r.m, m, sizeof(double) * 8);
+            } else {
+                const int j0 = local(where[gi][0]), j1 = local(where[gi][1]);
+                const int hi = std::max(j0, j1), lo = std::min(j0, j1);
+                r.code = 5 + hi * (hi - 1) / 2 + lo;
+                for (int rr = 0; rr < 4; ++rr)
+                    for (int cc = 0; cc < 4; ++cc) {
+                        // record index bit 1 <-> register bit hi; the caller's index bit 1 <-> leg 0
+                        const int ur = j0 > j1 ? rr : ((rr & 1) << 1) | (rr >> 1), uc = j0 > j1 ? cc : ((cc & 1) << 1) | (cc >> 1);
+                        r.m[2 * (rr * 4 + cc)] = m[2 * (ur * 4 + uc)];
+                        r.m[2 * (rr * 4 + cc) + 1] = m[2 * (ur * 4 + uc) + 1];
+                    }
+            }
+        }
+    }
+    std::vector<uint64_t> off(TILE_SEQ_ROWS, 0);
+    for (int row = 0; row < TILE_SEQ_ROWS; ++row)
+        for (int j = 0; j < TILE_SEQ_BITS - 6; ++j)
+            if ((row >> j) & 1) off[row] |= 1ull << tile_bits[6 + j];
+    // one image: [gates | passes | row offsets]
+    const size_t gates_bytes = qsv_pad16(sizeof(SeqGate) * rec.size()), passes_bytes = qsv_pad16(sizeof(TilePass) * passes.size());
+    std::vector<char> image(gates_bytes + passes_bytes, 0);
+    std::memcpy(image.data(), rec.data(), sizeof(SeqGate) * rec.size());
+    std::memcpy(image.data() + gates_bytes, passes.data(), sizeof(TilePass) * passes.size());
+    StageRef staged;
+    int rc = qsvk_stage(st, image.data(), image.size(), off.data(), sizeof(uint64_t) * off.size(), &staged);
+    if (rc) return rc;
+    const SeqGate *dev_g = reinterpret_cast<const SeqGate *>(staged.dev);
+    const TilePass *dev_p = reinterpret_cast<const TilePass *>(staged.dev + gates_bytes);
+    const uint64_t *dev_off = reinterpret_cast<const uint64_t *>(staged.dev + qsv_pad16(image.size()));
+    TileSeqArgs ta;
+    std::memset(&ta, 0, sizeof(ta));
+    BigArgs &g = ta.g;
+    g.W = st->amps >> TILE_SEQ_BITS;      // tiles: the index with every tile bit taken out
+    g.nins = TILE_SEQ_BITS;
+    for (int j = 0; j < TILE_SEQ_BITS; ++j) g.pos[j] = static_cast<uint32_t>(tile_bits[j]);
+    for (int j = 0; j < 6; ++j) ta.lane_bit[j] = static_cast<uint32_t>(tile_bits[j]);
+    g.regions = st->remap >= 0 ? static_cast<uint32_t>(st->remap) : 8;
+    const bool nt = st->nontemporal != 0;
+    const size_t lds = sizeof(amp_t) << TILE_SEQ_BITS;
+    static bool raised = false;
+    if (!raised) {
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_seq_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
+        QSV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_seq_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
+        raised = true;
+    }
+    snprintf(st->last_kernel, sizeof(st->last_kernel), "k_seq_tile<%s>", nt ? "true" : "false");
+    st->last_passes = static_cast<int>(passes.size());
+    const uint64_t per_launch = 1ull << 23;       // tiles per dispatch (a power of two: the tile order stays whole)
+    for (g.w0 = 0; g.w0 < g.W; g.w0 += per_launch) {
+        const uint64_t tiles = std::min(per_launch, g.W - g.w0);
+        const dim3 gd(static_cast<unsigned>(tiles)), bd(TILE_SEQ_THREADS);
+        if (nt) hipLaunchKernelGGL(k_seq_tile<true>, gd, bd, lds, st->stream, st->data, ta, dev_g, dev_p, static_cast<int>(passes.size()), dev_off);
+        else hipLaunchKernelGGL(k_seq_tile<false>, gd, bd, lds, st->stream, st->data, ta, dev_g, dev_p, static_cast<int>(passes.size()), dev_off);
         rc = check_launch();
         if (rc) return rc;
     }

@@ -15,6 +15,7 @@ import numpy as np
 from . import _lib
 
 _SEQUENCE_WORK_ENV = int(os.environ.get("QSV_SEQUENCE_WORK", "0") or 0)   # see DeviceState.apply_sequence
+_TILE_SEQUENCE_ENV = int(os.environ.get("QSV_TILE_SEQUENCE_GATES", "12") or 0)     # qsv_api.hip: qsv_apply_sequence
 
 
 def _cbuf(a, n_complex: int | None = None) -> np.ndarray:
@@ -163,6 +164,8 @@ class DeviceState:
         _lib.call("qsv_set_option", self._h, int(option), int(value))
         if int(option) == _lib.OPT_SEQUENCE_WORK:
             self._sequence_work = int(value) if int(value) >= 0 else _SEQUENCE_WORK_ENV
+        if int(option) == _lib.OPT_TILE_SEQUENCE_GATES:
+            self._tile_sequence_gates = int(value) if int(value) >= 0 else None
 
     def set_stream(self, stream: int) -> None:
         _lib.call("qsv_set_stream", self._h, C.c_void_p(stream))
@@ -186,12 +189,17 @@ class DeviceState:
 
     def apply_sequence(self, indices, sources, matrix) -> "DeviceState":
         """A fused block (``fusion.fuse_circuit``): ``matrix`` on qubits ``indices`` is the product of the gates
-        ``sources``.  With ``OPT_SEQUENCE_WORK`` (or ``$QSV_SEQUENCE_WORK``) set, 5-qubit blocks of 1- and 2-qubit gates
-        within that work limit are applied as that SEQUENCE in one pass over the register (``qsv_apply_sequence``: a
-        fraction of the dense block's arithmetic, but measured no faster -- off by default); everything else, and by
-        default every block, as the dense matrix."""
+        ``sources``.  6-qubit blocks made of at most 12 one- and two-qubit gates (``OPT_TILE_SEQUENCE_GATES``) are applied
+        as that LIST on LDS-resident tiles in one pass over the register (``qsv_apply_sequence`` -> ``k_seq_tile``: a
+        fraction of the dense block's arithmetic, 1.7-1.9 ms against 2.0-2.1); 5-qubit blocks only on request (tiles, or
+        the register form behind ``OPT_SEQUENCE_WORK``: neither beats their dense product); everything else as the dense
+        matrix."""
         indices = [int(i) for i in indices]
-        if getattr(self, "_sequence_work", _SEQUENCE_WORK_ENV) > 0 and len(indices) == 5 and all(getattr(g, "matrix", None) is not None and 1 <= len(g.indices) <= 2
+        requested = getattr(self, "_tile_sequence_gates", None)        # an explicit limit also admits 5-qubit blocks
+        on_tiles = (len(indices) == 6 or (len(indices) == 5 and requested is not None)) and \
+            len(sources) <= (_TILE_SEQUENCE_ENV if requested is None else requested)
+        in_registers = getattr(self, "_sequence_work", _SEQUENCE_WORK_ENV) > 0 and len(indices) == 5
+        if (on_tiles or in_registers) and all(getattr(g, "matrix", None) is not None and 1 <= len(g.indices) <= 2
                                      and np.shape(g.matrix) == (1 << len(g.indices),) * 2 for g in sources):
             arity = [len(g.indices) for g in sources]
             legs = []
@@ -200,8 +208,8 @@ class DeviceState:
                 legs += pos + [0] * (2 - len(pos))
             mats = np.concatenate([np.ascontiguousarray(g.matrix, dtype=np.complex128).reshape(-1) for g in sources])
             handled = C.c_int(0)
-            _lib.call("qsv_apply_sequence", self._h, 5, _ints(indices), len(sources), _ints(arity), _ints(legs), _ptr(mats),
-                      C.byref(handled))
+            _lib.call("qsv_apply_sequence", self._h, len(indices), _ints(indices), len(sources), _ints(arity), _ints(legs),
+                      _ptr(mats), C.byref(handled))
             if handled.value:
                 return self
         return self.apply_matrix(matrix, indices)

@@ -138,6 +138,29 @@ int main() {
             EXPECT(qsv_apply_sequence(st, 5, first.data(), 4, arity, legs, mats.data(), nullptr) == QSV_EINVAL);
             EXPECT(qsv_set_option(st, QSV_OPT_SEQUENCE_WORK, -1) == QSV_OK && qsv_set_option(st, QSV_OPT_SEQUENCE_WORK, -2) == QSV_EINVAL);
         }
+        // ---- 6-qubit blocks as gate lists on LDS tiles: on by default from 12 qubits up, every placement ---------------------
+        if (n >= 6) {
+            const int arity[5] = {2, 1, 2, 2, 1}, legs[10] = {0, 5, 3, 0, 2, 1, 4, 3, 5, 0};
+            std::vector<double> mats;
+            for (int a : arity) {
+                const std::vector<double> m = matrix(1 << a);
+                mats.insert(mats.end(), m.begin(), m.end());
+            }
+            int handled = 7;
+            for (int shift = 0; shift + 6 <= n; shift += (n > 14 ? 2 : 1)) {
+                std::vector<int> qs(6);
+                for (int j = 0; j < 6; ++j) qs[j] = shift + (j * 5 + 1) % 6;
+                EXPECT(qsv_apply_sequence(st, 6, qs.data(), 5, arity, legs, mats.data(), &handled) == QSV_OK);
+                EXPECT(handled == (n >= 12 ? 1 : 0));
+            }
+            std::vector<int> first = {5, 0, 2, 1, 3, 4};
+            EXPECT(qsv_set_option(st, QSV_OPT_TILE_SEQUENCE_GATES, 4) == QSV_OK);           // this list has five gates
+            EXPECT(qsv_apply_sequence(st, 6, first.data(), 5, arity, legs, mats.data(), &handled) == QSV_OK && handled == 0);
+            EXPECT(qsv_set_option(st, QSV_OPT_TILE_SEQUENCE_GATES, 0) == QSV_OK);
+            EXPECT(qsv_apply_sequence(st, 6, first.data(), 5, arity, legs, mats.data(), &handled) == QSV_OK && handled == 0);
+            EXPECT(qsv_set_option(st, QSV_OPT_TILE_SEQUENCE_GATES, 49) == QSV_EINVAL);
+            EXPECT(qsv_set_option(st, QSV_OPT_TILE_SEQUENCE_GATES, -1) == QSV_OK);
+        }
         // ---- controlled gates and multi-controlled phases with many controls --------------------------------------
         if (n >= 2) {
             for (int nc = 1; nc < n && nc <= 8; ++nc) {

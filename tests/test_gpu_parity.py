@@ -372,6 +372,62 @@ def test_fused_blocks_as_gate_sequences_every_low_target_set():
     assert a.last_kernel().startswith(("k_dense_big<5", "k_dense_lds<5")), a.last_kernel()
 
 
+@pytest.mark.parametrize("k", [5, 6])
+def test_fused_blocks_as_gate_lists_on_lds_tiles(k):
+    """Round 3: a fused block of 5 or 6 qubits applied as the LIST of its 1- and 2-qubit source gates on LDS-resident
+    4096-amplitude tiles (``qsv_apply_sequence`` -> ``k_seq_tile``) instead of its dense product: target sets with 0..k
+    qubits below bit 6 (every count, random choices), the others anywhere above, legs in any order, gates on every kind
+    of leg pair incl. CX / CZ / SWAP; against the oracle applying the source gates one by one.  n = 13 and 17 (one and
+    32 tiles per ... thousands of tiles)."""
+    from quantum_computations_amd.fusion import fuse_circuit
+    fixed = [G.CX, G.CZ, G.SWAP]
+    for n in (12, 13, 17):
+        rng = np.random.default_rng(100 * k + n)
+        ket = W.random_ket(n, 33)
+        dev = DeviceState.from_numpy(ket)
+        dev.set_option(_lib.OPT_TILE_SEQUENCE_GATES, 48)
+        want = ket
+        for trial in range(14):
+            n_low = trial % (k + 1)
+            low_bits = [int(b) for b in rng.choice(6, size=min(n_low, 6), replace=False)]
+            high_bits = [int(b) for b in rng.choice(np.arange(6, n), size=k - len(low_bits), replace=False)]
+            bits = low_bits + high_bits
+            rng.shuffle(bits)
+            qs = [n - 1 - b for b in bits]
+            sources = []
+            for _ in range(int(rng.integers(1, 9))):
+                if rng.random() < 0.45:
+                    sources.append(G.Gate([int(rng.choice(qs))], W.haar_unitary(2, rng)))
+                else:
+                    a, b = (int(q) for q in rng.choice(qs, size=2, replace=False))
+                    pick = int(rng.integers(0, 5))
+                    sources.append(fixed[pick](a, b) if pick < 3 else G.Gate([a, b], W.haar_unitary(4, rng)))
+            for i in range(0, k - 1, 2):                                       # every block touches all its qubits
+                sources.append(G.Gate([qs[i], qs[i + 1]], W.haar_unitary(4, rng)))
+            sources.append(G.Gate([qs[k - 1]], W.haar_unitary(2, rng)))
+            fused = fuse_circuit(sources, k, n_qubits=n)
+            assert len(fused) == 1 and sorted(fused[0].indices) == sorted(qs)
+            fused[0].apply(dev)
+            assert dev.last_kernel() == "k_seq_tile<true>", (bits, dev.last_kernel())
+            for g in sources:
+                want = O.apply_gate(want, np.asarray(g.matrix, dtype=complex), list(g.indices))
+            assert maxdiff(dev.to_numpy(), want) < CIRCUIT_TOL, (n, bits)
+        # the limit on the list length; 0 = never; registers below 12 qubits have no tile
+        block = fused[0]
+        dev.set_option(_lib.OPT_TILE_SEQUENCE_GATES, len(block.sources) - 1)
+        block.apply(dev)
+        assert not dev.last_kernel().startswith("k_seq_tile")
+        dev.set_option(_lib.OPT_TILE_SEQUENCE_GATES, 0)
+        block.apply(dev)
+        assert not dev.last_kernel().startswith("k_seq_tile")
+    small = DeviceState.from_numpy(W.random_ket(11, 1))
+    small.set_option(_lib.OPT_TILE_SEQUENCE_GATES, 48)
+    qs = list(range(k))
+    sources = [G.Gate([qs[i], qs[i + 1]], W.haar_unitary(4, np.random.default_rng(i))) for i in range(k - 1)]
+    fuse_circuit(sources, k, n_qubits=11)[0].apply(small)
+    assert not small.last_kernel().startswith("k_seq_tile")
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("k", [3, 4, 5])
 def test_register_blocked_kq_every_low_target_set(k, variant):
