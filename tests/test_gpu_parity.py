@@ -377,8 +377,9 @@ def test_fused_blocks_as_gate_lists_on_lds_tiles(k):
     """Round 3: a fused block of 5 or 6 qubits applied as the LIST of its 1- and 2-qubit source gates on LDS-resident
     4096-amplitude tiles (``qsv_apply_sequence`` -> ``k_seq_tile``) instead of its dense product: target sets with 0..k
     qubits below bit 6 (every count, random choices), the others anywhere above, legs in any order, gates on every kind
-    of leg pair incl. CX / CZ / SWAP; against the oracle applying the source gates one by one.  n = 13 and 17 (one and
-    32 tiles per ... thousands of tiles)."""
+    of leg pair incl. CX / CZ / SWAP; against the oracle applying the source gates one by one, on registers of 12, 13 and
+    17 qubits (1, 2 and 32 tiles).  An explicit limit admits 5-qubit blocks too; by default only 6-qubit blocks of at most
+    12 gates take this form."""
     from quantum_computations_amd.fusion import fuse_circuit
     fixed = [G.CX, G.CZ, G.SWAP]
     for n in (12, 13, 17):
