@@ -421,6 +421,10 @@ def test_fused_blocks_as_gate_lists_on_lds_tiles(k):
         dev.set_option(_lib.OPT_TILE_SEQUENCE_GATES, 0)
         block.apply(dev)
         assert not dev.last_kernel().startswith("k_seq_tile")
+    # the default: 6-qubit blocks of at most 12 gates on the tiles, 5-qubit blocks as their dense product
+    plain = DeviceState.from_numpy(W.random_ket(17, 2))
+    block.apply(plain)
+    assert plain.last_kernel().startswith("k_seq_tile") == (k == 6 and len(block.sources) <= 12), plain.last_kernel()
     small = DeviceState.from_numpy(W.random_ket(11, 1))
     small.set_option(_lib.OPT_TILE_SEQUENCE_GATES, 48)
     qs = list(range(k))
