@@ -1,6 +1,6 @@
 """Fused 5-qubit blocks of the cfg2 circuit: dense product vs the sequence of their source gates, by work limit.
 
-    python3 tools/probe_sequence.py [n_qubits] [steps] [max block qubits]
+    python3 tools/probe_sequence.py [n_qubits] [steps] [max block qubits] [tile regions]
 
 One JSON line per setting of QSV_OPT_SEQUENCE_WORK (0 = every block as its dense product): gate-apps/s of the fused
 circuit, how many blocks went as sequences, and the mean time per block of each kernel family (host clock around every
@@ -32,6 +32,8 @@ def main() -> None:
                       "gates_per_block": [len(getattr(b, "sources", [b])) for b in fused]}), flush=True)
     dev = DeviceState.zeros(n)
     dev.fill_random(28)
+    if len(sys.argv) > 4:
+        dev.set_option(_lib.OPT_TILE_REGIONS, int(sys.argv[4]))       # tile order of every tile kernel (-1 = built-in rules)
     settings = [("work", w) for w in (0, 2048, 3072, 1 << 20)] if k == 5 else [("work", 0)]
     settings += [("tile_gates", g) for g in (4, 6, 8, 10, 12, 16, 48)]
     for kind, limit in settings:
