@@ -15,6 +15,7 @@ import numpy as np
 from . import _lib
 
 _SEQUENCE_WORK_ENV = int(os.environ.get("QSV_SEQUENCE_WORK", "0") or 0)   # see DeviceState.apply_sequence
+_PACKED_SEQUENCES: dict = {}     # id(sources list of a fused block) -> its packed gate list, see DeviceState.apply_sequence
 _TILE_SEQUENCE_ENV = int(os.environ.get("QSV_TILE_SEQUENCE_GATES", "12") or 0)     # qsv_api.hip: qsv_apply_sequence
 
 
@@ -201,15 +202,21 @@ class DeviceState:
         in_registers = getattr(self, "_sequence_work", _SEQUENCE_WORK_ENV) > 0 and len(indices) == 5
         if (on_tiles or in_registers) and all(getattr(g, "matrix", None) is not None and 1 <= len(g.indices) <= 2
                                      and np.shape(g.matrix) == (1 << len(g.indices),) * 2 for g in sources):
-            arity = [len(g.indices) for g in sources]
-            legs = []
-            for g in sources:
-                pos = [indices.index(int(q)) for q in g.indices]
-                legs += pos + [0] * (2 - len(pos))
-            mats = np.concatenate([np.ascontiguousarray(g.matrix, dtype=np.complex128).reshape(-1) for g in sources])
+            packed = _PACKED_SEQUENCES.get(id(sources))
+            if packed is None or packed[0] is not sources or packed[1] != indices or packed[6] != len(sources):
+                arity = [len(g.indices) for g in sources]
+                legs = []
+                for g in sources:
+                    pos = [indices.index(int(q)) for q in g.indices]
+                    legs += pos + [0] * (2 - len(pos))
+                mats = np.concatenate([np.ascontiguousarray(g.matrix, dtype=np.complex128).reshape(-1) for g in sources])
+                packed = (sources, list(indices), _ints(indices), _ints(arity), _ints(legs), mats, len(sources))
+                if len(_PACKED_SEQUENCES) >= 512:
+                    _PACKED_SEQUENCES.clear()
+                _PACKED_SEQUENCES[id(sources)] = packed       # a fused block is applied many times: pack its list once
             handled = C.c_int(0)
-            _lib.call("qsv_apply_sequence", self._h, len(indices), _ints(indices), len(sources), _ints(arity), _ints(legs),
-                      _ptr(mats), C.byref(handled))
+            _lib.call("qsv_apply_sequence", self._h, len(indices), packed[2], len(sources), packed[3], packed[4],
+                      _ptr(packed[5]), C.byref(handled))
             if handled.value:
                 return self
         return self.apply_matrix(matrix, indices)
